@@ -1,0 +1,15 @@
+"""MI355X-native radiance core for rweyrauch/gpupathtracer's hot path.
+
+The product is the C-ABI shared library ``libptcore.so`` (declared in ``include/ptcore.h``,
+built from ``gpupathtracer_amd/csrc`` for gfx950).  This package is a thin ctypes binding over
+that ABI for tests and benchmarks; it contains no rendering code of its own and raises if the
+library has not been built -- there is no CPU fallback.
+"""
+from .api import (  # noqa: F401
+    PtError, Scene, SceneDesc, RenderStats, builtin_scene, trimesh_scene, device_count,
+    library, library_path,
+)
+from . import _abi as abi  # noqa: F401
+
+__all__ = ["PtError", "Scene", "SceneDesc", "RenderStats", "builtin_scene", "trimesh_scene",
+           "device_count", "library", "library_path", "abi"]

@@ -1,0 +1,196 @@
+"""ctypes binding of the C ABI in include/ptcore.h.
+
+Mirrors the seam of the reference's main() (src/ptMain.cu:559-653): build a scene
+(``builtin_scene`` ~ the hard-coded scene call at :559), hand it to the device
+(``Scene`` ~ serialise + allocate_world_kernel, :560-610) and render (``Scene.render`` ~
+render_kernel + cudaMemcpy, :612-649).  Errors surface as ``PtError`` carrying the library's
+message, where the reference prints to std::cerr and exits.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptcore.so")
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("ptcore error %d: %s" % (code, message))
+        self.code = code
+
+
+def library():
+    """Loads libptcore.so (once).  Raises if it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `make -C gpupathtracer_amd/csrc` "
+            "(or __graft_entry__.build()); this package has no CPU path" % path)
+    lib = C.CDLL(path)
+    P = C.POINTER
+    lib.pt_last_error.restype = C.c_char_p
+    lib.pt_last_error.argtypes = []
+    lib.pt_scene_create.argtypes = [P(A.PtSceneDesc), P(C.c_void_p)]
+    lib.pt_scene_destroy.argtypes = [C.c_void_p]
+    lib.pt_scene_destroy.restype = None
+    lib.pt_render.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p]
+    lib.pt_render_device.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_void_p]
+    lib.pt_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.pt_render_stats.argtypes = [C.c_void_p, P(A.PtRenderStats)]
+    lib.pt_scene_lbvh_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.pt_scene_desc_builtin.argtypes = [C.c_char_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                          P(P(A.PtSceneDesc))]
+    lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
+    lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
+    lib.pt_scene_desc_free.restype = None
+    lib.pt_device_count.argtypes = []
+    _LIB = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtError(rc, library().pt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(library().pt_device_count())
+
+
+class SceneDesc:
+    """Owns a library-allocated PtSceneDesc (one of the reference's scenes)."""
+
+    def __init__(self, ptr):
+        self._ptr = ptr
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+    @property
+    def c(self):
+        return self._ptr.contents
+
+    def close(self):
+        if self._ptr is not None:
+            library().pt_scene_desc_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def builtin_scene(name, aspect, earth_rgb=None, accel=None):
+    """One of simple_spheres, simple_light, random, cornell, cornell_spheres, final, trimesh
+    (src/ptMain.cu:192-421).  earth_rgb: optional HxWx3 uint8 texels for ``final``."""
+    lib = library()
+    out = C.POINTER(A.PtSceneDesc)()
+    if earth_rgb is not None:
+        tex = np.ascontiguousarray(earth_rgb, dtype=np.uint8)
+        assert tex.ndim == 3 and tex.shape[2] == 3
+        _check(lib.pt_scene_desc_builtin(name.encode(), float(aspect), tex.ctypes.data, tex.shape[1], tex.shape[0],
+                                         C.byref(out)))
+    else:
+        _check(lib.pt_scene_desc_builtin(name.encode(), float(aspect), None, 0, 0, C.byref(out)))
+    if accel is not None:
+        out.contents.accel = int(accel)
+    return SceneDesc(out)
+
+
+def trimesh_scene(grid_n, aspect):
+    lib = library()
+    out = C.POINTER(A.PtSceneDesc)()
+    _check(lib.pt_scene_desc_trimesh(int(grid_n), float(aspect), C.byref(out)))
+    return SceneDesc(out)
+
+
+class RenderStats:
+    def __init__(self, s):
+        self.kernel_ms = float(s.kernel_ms)
+        self.total_ms = float(s.total_ms)
+        self.n_launches = int(s.n_launches)
+        self.pipeline = int(s.pipeline)
+        self.paths = int(s.paths)
+
+
+def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0):
+    return A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=shard_index,
+                            shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline)
+
+
+class Scene:
+    """A scene resident on the current HIP device."""
+
+    def __init__(self, desc):
+        lib = library()
+        h = C.c_void_p()
+        ptr = desc.ptr if isinstance(desc, SceneDesc) else desc
+        _check(lib.pt_scene_create(ptr, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            library().pt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, nx, ny, ns, max_depth=25, **kw):
+        """Returns the (ny, nx, 3) float32 frame on the host; row 0 is the top of the image."""
+        p = make_params(nx, ny, ns, max_depth, **kw)
+        out = np.empty((ny, nx, 3), np.float32)
+        _check(library().pt_render(self._h, C.byref(p), out.ctypes.data))
+        return out
+
+    def render_device(self, d_out_ptr, nx, ny, ns, max_depth=25, stream=None, **kw):
+        """Queues a render into device memory (d_out_ptr: integer device address of nx*ny*3 floats)."""
+        p = make_params(nx, ny, ns, max_depth, **kw)
+        _check(library().pt_render_device(self._h, C.byref(p), C.c_void_p(d_out_ptr),
+                                          C.c_void_p(stream) if stream else None))
+
+    def stats(self):
+        s = A.PtRenderStats()
+        _check(library().pt_render_stats(self._h, C.byref(s)))
+        return RenderStats(s)
+
+    def trace_closest(self, rays):
+        """rays: structured/packed array of PtRay (n x 32 bytes).  Returns (prim_id int32[n], t float32[n])."""
+        rays = np.ascontiguousarray(rays)
+        assert rays.nbytes % 32 == 0
+        n = rays.nbytes // 32
+        ids = np.empty(n, np.int32)
+        ts = np.empty(n, np.float32)
+        _check(library().pt_trace_closest(self._h, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data))
+        return ids, ts
+
+    def lbvh_nodes(self):
+        """The library-built LBVH as an (n, 16) uint32 view of its 64-byte nodes (empty if none)."""
+        n = library().pt_scene_lbvh_nodes(self._h, None, 0)
+        if n < 0:
+            _check(n)
+        buf = np.zeros((max(n, 0), 16), np.uint32)
+        if n > 0:
+            rc = library().pt_scene_lbvh_nodes(self._h, buf.ctypes.data, buf.nbytes)
+            if rc < 0:
+                _check(rc)
+        return buf
+
+
+RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3), ("time", np.float32), ("seed", np.uint32)])

@@ -1,0 +1,529 @@
+// Radiance kernels for gfx950 and the C-ABI entry points that launch them (include/ptcore.h).
+//
+// The reference's device side is one megakernel, one thread per pixel, all samples and bounces
+// in nested loops behind virtual calls (render_kernel, src/ptMain.cu:171-190).  Here:
+//   * k_render_fused: one lane per pixel, one loop iteration per BOUNCE; a lane whose path ended
+//     accumulates it and regenerates the next camera sample inside the same loop, so the 64 lanes
+//     of a wave stay busy although their paths have different lengths.  The pixel's PCG stream is
+//     carried in registers across samples and bounces exactly as render_pixel does
+//     (src/ptMain.cu:153-169), which is what makes images comparable sample for sample.
+//   * k_trace_closest: world->hit for a batch of rays (closest-hit parity entry point).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_device.h"
+#include "pt_host.h"
+#include "pt_lbvh.h"
+
+using namespace ptd;
+
+// ---- kernels ----------------------------------------------------------------------------------------
+
+struct RenderArgs {
+    int32_t nx, ny, ns, max_depth;
+    int32_t shard_index, shard_count;
+    int32_t tile_w, tile_h;        // shard tile size in pixels
+    int32_t tiles_x;               // tiles per image row
+    int32_t n_tiles;               // all tiles of the image
+    int32_t sub_x, sub_y;          // 8x8 wave tiles per shard tile
+    int32_t n_wave_tiles;          // wave tiles owned by this shard
+};
+
+// Wave w of the launch -> its 8x8 pixel block.  Shard tiles owned by this shard are
+// tile = shard_index + k * shard_count; each is cut into sub_x * sub_y wave tiles.
+__device__ __forceinline__ bool wave_pixel(const RenderArgs& ra, int wave, int lane, int& x, int& ytop)
+{
+    const int per_tile = ra.sub_x * ra.sub_y;
+    const int k = wave / per_tile, sub = wave - k * per_tile;
+    const int tile = ra.shard_index + k * ra.shard_count;
+    const int ty = tile / ra.tiles_x, tx = tile - ty * ra.tiles_x;
+    const int sy = sub / ra.sub_x, sx = sub - sy * ra.sub_x;
+    const int lx = sx * 8 + (lane & 7), ly = sy * 8 + (lane >> 3);
+    x = tx * ra.tile_w + lx;
+    ytop = ty * ra.tile_h + ly;
+    return lx < ra.tile_w && ly < ra.tile_h && x < ra.nx && ytop < ra.ny;
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_render_fused(SceneView sv, RenderArgs ra, float* __restrict__ out)
+{
+    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wave_in_block;
+    if (wave >= ra.n_wave_tiles) return;
+    int x, ytop;
+    if (!wave_pixel(ra, wave, lane, x, ytop)) return;
+    int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+
+    const int y = ra.ny - 1 - ytop;                       // render_kernel's y: row 0 of the image is the top
+    const unsigned i = (unsigned)(ytop * ra.nx + x);      // = (ny - y - 1) * nx + x   (src/ptMain.cu:178)
+    Pcg rng;
+    rng.seed(i);                                          // PcgRng rng(i)              (src/ptMain.cu:183)
+
+    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    V3 accum = mk(0, 0, 0);
+    V3 thr = mk(1, 1, 1);
+    Ray ray;
+    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.time = 0;
+    int s = 0, depth = 0;
+    bool fresh = true;
+    while (s < ra.ns) {
+        if (fresh) {                                      // render_pixel, src/ptMain.cu:158-160
+            float u = ((float)x + rng.rand()) / fnx;
+            float v = ((float)y + rng.rand()) / fny;
+            ray = camera_ray(sv, u, v, rng);
+            thr = mk(1, 1, 1);
+            depth = 0;
+            fresh = false;
+        }
+        bool ended;
+        if (depth >= ra.max_depth) {
+            ended = true;                                 // bounce limit: color() returns the running product
+        } else {
+            Hit h;
+            if (world_hit<F>(sv, ray, 0.001f, FLT_MAX, h, rng, my_stack)) {
+                ended = !shade<F>(sv, ray, h, thr, rng);
+            } else {
+                shade_miss<F>(sv, ray, thr);
+                ended = true;
+            }
+            depth++;
+        }
+        if (ended) {                                      // accumCol += deNan(color(...)), src/ptMain.cu:46-53,161
+            if (!(thr.x == thr.x)) thr.x = 0;
+            if (!(thr.y == thr.y)) thr.y = 0;
+            if (!(thr.z == thr.z)) thr.z = 0;
+            accum = accum + thr;
+            s++;
+            fresh = true;
+        }
+    }
+    const float inv_ns = 1 / (float)ra.ns;                // accumCol /= float(ns): reciprocal, then multiplies
+    accum = mk(accum.x * inv_ns, accum.y * inv_ns, accum.z * inv_ns);
+    out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, accum.x));
+    out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, accum.y));
+    out[3 * (size_t)i + 2] = sqrtf(fmaxf(0.0f, accum.z));
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay* __restrict__ rays, size_t n,
+                                                       int32_t* __restrict__ prim_id, float* __restrict__ t_out)
+{
+    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int* my_stack = (F & F_LBVH) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
+    const PtRay pr = rays[i];
+    Ray r;
+    r.o = mk(pr.o[0], pr.o[1], pr.o[2]);
+    r.d = mk(pr.d[0], pr.d[1], pr.d[2]);
+    r.time = pr.time;
+    Pcg rng;
+    rng.seed(pr.seed);
+    Hit h;
+    if (world_hit<F>(sv, r, 0.001f, FLT_MAX, h, rng, my_stack)) { prim_id[i] = h.id; t_out[i] = h.t; }
+    else { prim_id[i] = PT_ID_MISS; t_out[i] = FLT_MAX; }
+}
+
+// ---- feature-mask specialisations ---------------------------------------------------------------------
+
+namespace {
+
+constexpr uint32_t M_CORNELL = F_RECT | F_BOX | F_XFORM | F_LIGHTS;
+constexpr uint32_t M_SPHERES = F_SPHERE | F_MSPHERE | F_METAL | F_DIELECTRIC | F_CHECKER | F_SKY;
+constexpr uint32_t M_SPHERES_LBVH = M_SPHERES | F_LBVH;
+constexpr uint32_t M_TRIMESH = F_RECT | F_TRIANGLE | F_LIGHTS | F_LBVH;
+constexpr uint32_t M_ALL = F_ALL & ~F_LBVH;
+constexpr uint32_t M_ALL_LBVH = F_ALL;
+
+const uint32_t k_masks[] = { M_CORNELL, M_SPHERES, M_SPHERES_LBVH, M_TRIMESH, M_ALL, M_ALL_LBVH };
+
+int pick_variant(uint32_t scene_mask)
+{
+    for (int v = 0; v < (int)(sizeof(k_masks) / sizeof(k_masks[0])); v++) {
+        const uint32_t m = k_masks[v];
+        if ((scene_mask & ~m) == 0 && ((m ^ scene_mask) & F_LBVH) == 0) return v;
+    }
+    return -1;
+}
+
+void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, hipStream_t st)
+{
+    const dim3 block(256), grid((ra.n_wave_tiles + 3) / 4);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(k_render_fused<M_CORNELL>, grid, block, 0, st, sv, ra, out); break;
+    case 1: hipLaunchKernelGGL(k_render_fused<M_SPHERES>, grid, block, 0, st, sv, ra, out); break;
+    case 2: hipLaunchKernelGGL(k_render_fused<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, out); break;
+    case 3: hipLaunchKernelGGL(k_render_fused<M_TRIMESH>, grid, block, 0, st, sv, ra, out); break;
+    case 4: hipLaunchKernelGGL(k_render_fused<M_ALL>, grid, block, 0, st, sv, ra, out); break;
+    default: hipLaunchKernelGGL(k_render_fused<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out); break;
+    }
+}
+
+void launch_trace(int variant, const SceneView& sv, const PtRay* rays, size_t n, int32_t* ids, float* ts, hipStream_t st)
+{
+    const dim3 block(256), grid((unsigned)((n + 255) / 256));
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(k_trace_closest<M_CORNELL>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+    case 1: hipLaunchKernelGGL(k_trace_closest<M_SPHERES>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+    case 2: hipLaunchKernelGGL(k_trace_closest<M_SPHERES_LBVH>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+    case 3: hipLaunchKernelGGL(k_trace_closest<M_TRIMESH>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+    case 4: hipLaunchKernelGGL(k_trace_closest<M_ALL>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+    default: hipLaunchKernelGGL(k_trace_closest<M_ALL_LBVH>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+    }
+}
+
+}  // namespace
+
+// ---- host side of the C ABI --------------------------------------------------------------------------
+
+struct PtScene {
+    int device = 0;
+    SceneView view{};
+    std::vector<void*> allocs;          // every device allocation of this scene
+    uint32_t mask = 0;
+    int variant = -1;
+    int n_shapes = 0, n_media = 0;
+    int lbvh_nodes = 0;
+    // timing of the most recent render
+    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+    bool have_timing = false;
+    PtRenderStats last{};
+};
+
+namespace {
+
+bool hip_ok(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return true;
+    std::string msg = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+    pt::set_error(msg.c_str());
+    return false;
+}
+
+template <class T>
+bool upload(PtScene* sc, const T* src, size_t n, const T** dst, const char* what)
+{
+    *dst = nullptr;
+    if (n == 0) return true;
+    void* d = nullptr;
+    if (!hip_ok(hipMalloc(&d, n * sizeof(T)), what)) return false;
+    sc->allocs.push_back(d);
+    if (!hip_ok(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice), what)) return false;
+    *dst = static_cast<const T*>(d);
+    return true;
+}
+
+bool fail(const char* msg) { pt::set_error(msg); return false; }
+
+// Structural validation: every index in range, trees acyclic and shallow enough for the
+// fixed traversal stacks.  A kernel must never see an index it could fault on.
+bool validate(const PtSceneDesc* d, uint32_t* mask_out)
+{
+    uint32_t mask = 0;
+    if (d->n_shapes < 0 || d->n_world <= 0 || d->n_materials < 0 || d->n_textures < 0) return fail("scene: negative or empty counts");
+    if ((d->n_shapes && !d->shapes) || !d->world || (d->n_materials && !d->materials) || (d->n_textures && !d->textures))
+        return fail("scene: null array with non-zero count");
+    if ((d->n_xforms && !d->xforms) || (d->n_media && !d->media) || (d->n_bvh_nodes && !d->bvh_nodes) || (d->n_bvhs && !d->bvhs) ||
+        (d->n_lights && !d->lights) || (d->n_texels && !d->texels) || (d->n_tri_uvs && !d->tri_uvs))
+        return fail("scene: null array with non-zero count");
+    for (int i = 0; i < d->n_textures; i++) {
+        const PtTexture& t = d->textures[i];
+        switch (t.type) {
+        case PT_TEX_CONSTANT: break;
+        case PT_TEX_CHECKER:
+            if (t.odd < 0 || t.odd >= d->n_textures || t.even < 0 || t.even >= d->n_textures) return fail("texture: checker child out of range");
+            if (t.odd >= i || t.even >= i) return fail("texture: checker children must precede the checker");
+            mask |= F_CHECKER; break;
+        case PT_TEX_NOISE: mask |= F_NOISE; break;
+        case PT_TEX_IMAGE:
+            if (t.nx <= 0 || t.ny <= 0 || t.texel_offset < 0 || (int64_t)t.texel_offset + (int64_t)3 * t.nx * t.ny > d->n_texels)
+                return fail("texture: image texels out of range");
+            mask |= F_IMAGE; break;
+        default: return fail("texture: unknown type");
+        }
+    }
+    for (int i = 0; i < d->n_materials; i++) {
+        const PtMaterial& m = d->materials[i];
+        const bool needs_tex = m.type == PT_MAT_LAMBERTIAN || m.type == PT_MAT_DIFFUSE_LIGHT || m.type == PT_MAT_ISOTROPIC;
+        if (needs_tex && (m.texture < 0 || m.texture >= d->n_textures)) return fail("material: texture out of range");
+        switch (m.type) {
+        case PT_MAT_LAMBERTIAN: case PT_MAT_DIFFUSE_LIGHT: break;
+        case PT_MAT_METAL: mask |= F_METAL; break;
+        case PT_MAT_DIELECTRIC: mask |= F_DIELECTRIC; break;
+        case PT_MAT_ISOTROPIC: mask |= F_ISOTROPIC; break;
+        default: return fail("material: unknown type");
+        }
+    }
+    for (int i = 0; i < d->n_xforms; i++)
+        if (d->xforms[i].type != PT_XFORM_TRANSLATE && d->xforms[i].type != PT_XFORM_ROTATE_Y) return fail("xform: unknown type");
+    for (int i = 0; i < d->n_shapes; i++) {
+        const PtShape& s = d->shapes[i];
+        if (s.material < -1 || s.material >= d->n_materials) return fail("shape: material out of range");
+        if (s.xform_count < 0 || s.xform_first < 0 || (int64_t)s.xform_first + s.xform_count > d->n_xforms) return fail("shape: xform range out of bounds");
+        if (s.xform_count > 0) mask |= F_XFORM;
+        switch (s.type) {
+        case PT_SHAPE_SPHERE: mask |= F_SPHERE; break;
+        case PT_SHAPE_MOVING_SPHERE: mask |= F_MSPHERE; break;
+        case PT_SHAPE_RECT_XY: case PT_SHAPE_RECT_XZ: case PT_SHAPE_RECT_YZ: mask |= F_RECT; break;
+        case PT_SHAPE_BOX: mask |= F_BOX; break;
+        case PT_SHAPE_TRIANGLE:
+            if (s.tri_uv < -1 || s.tri_uv >= d->n_tri_uvs) return fail("shape: tri_uv out of range");
+            mask |= F_TRIANGLE; break;
+        default: return fail("shape: unknown type");
+        }
+    }
+    auto world_shape_ok = [&](int idx) { return idx >= 0 && idx < d->n_shapes && d->shapes[idx].material >= 0; };
+    for (int i = 0; i < d->n_media; i++) {
+        const PtMedium& m = d->media[i];
+        if (m.boundary < 0 || m.boundary >= d->n_shapes) return fail("medium: boundary out of range");
+        if (m.material < 0 || m.material >= d->n_materials) return fail("medium: material out of range");
+    }
+    // explicit trees: children must have smaller indices than their parent (the builder's
+    // post-order), which rules out cycles; depth is bounded for the traversal stack
+    std::vector<int> depth((size_t)d->n_bvh_nodes, 0);
+    for (int i = 0; i < d->n_bvh_nodes; i++) {
+        const PtBvhNode& n = d->bvh_nodes[i];
+        int dl = 0, dr = 0;
+        for (int side = 0; side < 2; side++) {
+            const int c = side ? n.right : n.left;
+            if (c >= 0) {
+                if (c >= i) return fail("bvh: child index must be smaller than its parent's");
+                (side ? dr : dl) = depth[c];
+            } else if (!world_shape_ok(~c)) return fail("bvh: leaf shape out of range or without material");
+        }
+        depth[i] = 1 + (dl > dr ? dl : dr);
+        if (depth[i] >= REFBVH_STACK) return fail("bvh: tree deeper than the traversal stack");
+    }
+    for (int i = 0; i < d->n_bvhs; i++) {
+        const PtBvh& b = d->bvhs[i];
+        if (b.root < 0 || b.root >= d->n_bvh_nodes) return fail("bvh: root out of range");
+        if (b.xform_count < 0 || b.xform_first < 0 || (int64_t)b.xform_first + b.xform_count > d->n_xforms) return fail("bvh: xform range out of bounds");
+        if (b.xform_count > 0) mask |= F_XFORM;
+    }
+    for (int i = 0; i < d->n_world; i++) {
+        const PtObject& o = d->world[i];
+        if (o.type == PT_OBJ_SHAPE) { if (!world_shape_ok(o.index)) return fail("world: shape out of range or without material"); }
+        else if (o.type == PT_OBJ_MEDIUM) { if (o.index < 0 || o.index >= d->n_media) return fail("world: medium out of range"); mask |= F_MEDIUM; }
+        else if (o.type == PT_OBJ_BVH) { if (o.index < 0 || o.index >= d->n_bvhs) return fail("world: bvh out of range"); mask |= F_REFBVH; }
+        else return fail("world: unknown object type");
+    }
+    if (d->n_lights < 0) return fail("lights: negative count");
+    if (d->n_lights > 0) {
+        mask |= F_LIGHTS;
+        for (int i = 0; i < d->n_lights; i++)
+            if (d->lights[i] < 0 || d->lights[i] >= d->n_shapes) return fail("lights: shape out of range");
+        const PtShape& l0 = d->shapes[d->lights[0]];
+        if (d->lights_is_list || d->n_lights > 1 || l0.type != PT_SHAPE_RECT_XZ || l0.xform_count != 0) mask |= F_LIGHT_MISC;
+        if (!d->lights_is_list && d->n_lights != 1) return fail("lights: more than one light shape needs lights_is_list");
+    }
+    if (d->ambient_type == PT_AMBIENT_SKY) mask |= F_SKY;
+    else if (d->ambient_type != PT_AMBIENT_NONE && d->ambient_type != PT_AMBIENT_CONSTANT) return fail("ambient: unknown type");
+    *mask_out = mask;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
+{
+    if (!desc || !out_scene) { pt::set_error("pt_scene_create: null argument"); return PT_ERR_INVALID; }
+    *out_scene = nullptr;
+    uint32_t mask = 0;
+    if (!validate(desc, &mask)) return PT_ERR_INVALID;
+    if (pt_device_count() <= 0) { pt::set_error("pt_scene_create: no HIP device is visible"); return PT_ERR_NO_DEVICE; }
+
+    PtScene* sc = new PtScene();
+    if (!hip_ok(hipGetDevice(&sc->device), "hipGetDevice")) { delete sc; return PT_ERR_HIP; }
+    SceneView& v = sc->view;
+    bool ok = upload(sc, desc->shapes, (size_t)desc->n_shapes, &v.shapes, "upload shapes")
+           && upload(sc, desc->tri_uvs, (size_t)desc->n_tri_uvs, &v.tri_uvs, "upload tri_uvs")
+           && upload(sc, desc->xforms, (size_t)desc->n_xforms, &v.xforms, "upload xforms")
+           && upload(sc, desc->materials, (size_t)desc->n_materials, &v.materials, "upload materials")
+           && upload(sc, desc->textures, (size_t)desc->n_textures, &v.textures, "upload textures")
+           && upload(sc, desc->texels, (size_t)desc->n_texels, &v.texels, "upload texels")
+           && upload(sc, desc->media, (size_t)desc->n_media, &v.media, "upload media")
+           && upload(sc, desc->bvh_nodes, (size_t)desc->n_bvh_nodes, &v.bvh_nodes, "upload bvh nodes")
+           && upload(sc, desc->bvhs, (size_t)desc->n_bvhs, &v.bvhs, "upload bvhs")
+           && upload(sc, desc->world, (size_t)desc->n_world, &v.world, "upload world")
+           && upload(sc, desc->lights, (size_t)desc->n_lights, &v.lights, "upload lights");
+    if (!ok) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+    v.n_world = desc->n_world;
+    v.n_lights = desc->n_lights;
+    v.lights_is_list = desc->lights_is_list;
+    v.ambient_type = desc->ambient_type;
+    std::memcpy(v.ambient, desc->ambient_color, sizeof v.ambient);
+    std::memcpy(v.camera, desc->camera, sizeof v.camera);
+    v.lbvh = nullptr; v.lbvh_root = 0; v.lbvh_cull = 0;
+    sc->n_shapes = desc->n_shapes;
+    sc->n_media = desc->n_media;
+
+    // Library-built LBVH over the world list (in place of BVH::BVH + quickSort).
+    const bool list_only_shapes = !(mask & (F_MEDIUM | F_REFBVH));
+    if (desc->accel == PT_ACCEL_LBVH && list_only_shapes && desc->n_world >= 2) {
+        void* d_nodes = nullptr;
+        int n_nodes = 0, root = 0;
+        const int rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
+        if (rc != PT_OK) { pt_scene_destroy(sc); return rc; }
+        sc->allocs.push_back(d_nodes);
+        v.lbvh = static_cast<const LbvhNode*>(d_nodes);
+        v.lbvh_root = root;
+        v.lbvh_cull = (mask & F_TRIANGLE) ? 0 : 1;
+        sc->lbvh_nodes = n_nodes;
+        mask |= F_LBVH;
+    }
+    sc->mask = mask;
+    sc->variant = pick_variant(mask);
+    if (sc->variant < 0) { pt::set_error("pt_scene_create: no kernel specialisation covers this scene"); pt_scene_destroy(sc); return PT_ERR_UNSUPPORTED; }
+    ok = hip_ok(hipEventCreate(&sc->ev_begin), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_k0), "hipEventCreate")
+      && hip_ok(hipEventCreate(&sc->ev_k1), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_end), "hipEventCreate");
+    if (!ok) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+    *out_scene = sc;
+    return PT_OK;
+}
+
+extern "C" void pt_scene_destroy(PtScene* sc)
+{
+    if (!sc) return;
+    for (void* p : sc->allocs) (void)hipFree(p);
+    if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
+    if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);
+    if (sc->ev_k1) (void)hipEventDestroy(sc->ev_k1);
+    if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
+    delete sc;
+}
+
+namespace {
+
+bool make_args(const PtRenderParams* p, RenderArgs* ra)
+{
+    if (p->nx <= 0 || p->ny <= 0 || p->ns <= 0 || p->max_depth < 0) return fail("render: nx, ny, ns must be positive and max_depth non-negative");
+    if ((int64_t)p->nx * p->ny > (int64_t)1 << 30) return fail("render: image too large");
+    const int sc = p->shard_count > 0 ? p->shard_count : 1;
+    if (p->shard_index < 0 || p->shard_index >= sc) return fail("render: shard_index out of range");
+    const int tw = p->tile_w > 0 ? p->tile_w : 8, th = p->tile_h > 0 ? p->tile_h : 8;
+    ra->nx = p->nx; ra->ny = p->ny; ra->ns = p->ns; ra->max_depth = p->max_depth;
+    ra->shard_index = p->shard_index; ra->shard_count = sc;
+    ra->tile_w = tw; ra->tile_h = th;
+    ra->tiles_x = (p->nx + tw - 1) / tw;
+    const int tiles_y = (p->ny + th - 1) / th;
+    ra->n_tiles = ra->tiles_x * tiles_y;
+    ra->sub_x = (tw + 7) / 8; ra->sub_y = (th + 7) / 8;
+    const int owned = (ra->n_tiles - p->shard_index + sc - 1) / sc;     // tiles t with t % sc == shard_index
+    ra->n_wave_tiles = owned * ra->sub_x * ra->sub_y;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream)
+{
+    if (!sc || !p || !d_out_rgb) { pt::set_error("pt_render_device: null argument"); return PT_ERR_INVALID; }
+    RenderArgs ra;
+    if (!make_args(p, &ra)) return PT_ERR_INVALID;
+    if (p->pipeline != PT_PIPELINE_DEFAULT && p->pipeline != PT_PIPELINE_FUSED && p->pipeline != PT_PIPELINE_WAVEFRONT) {
+        pt::set_error("render: unknown pipeline"); return PT_ERR_INVALID;
+    }
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT) { pt::set_error("render: the wavefront scheduler is not available in this build"); return PT_ERR_UNSUPPORTED; }
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    float* out = static_cast<float*>(d_out_rgb);
+    if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
+    // pixels this shard does not own must read as zero so that shards sum to the frame
+    if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
+    if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
+    if (ra.n_wave_tiles > 0) launch_render(sc->variant, sc->view, ra, out, st);
+    if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
+    if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
+    if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
+    sc->have_timing = true;
+    sc->last = PtRenderStats{};
+    sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
+    sc->last.pipeline = PT_PIPELINE_FUSED;
+    // paths = owned pixels x ns
+    uint64_t owned_px = 0;
+    {
+        const int tiles_y = (p->ny + ra.tile_h - 1) / ra.tile_h;
+        for (int t = ra.shard_index; t < ra.n_tiles; t += ra.shard_count) {
+            const int ty = t / ra.tiles_x, tx = t % ra.tiles_x;
+            const int w = std::min(ra.tile_w, p->nx - tx * ra.tile_w), h = std::min(ra.tile_h, p->ny - ty * ra.tile_h);
+            owned_px += (uint64_t)w * (uint64_t)h;
+        }
+        (void)tiles_y;
+    }
+    sc->last.paths = owned_px * (uint64_t)p->ns;
+    return PT_OK;
+}
+
+extern "C" int pt_render(PtScene* sc, const PtRenderParams* p, float* out_rgb)
+{
+    if (!sc || !p || !out_rgb) { pt::set_error("pt_render: null argument"); return PT_ERR_INVALID; }
+    if (p->nx <= 0 || p->ny <= 0) { pt::set_error("render: nx, ny must be positive"); return PT_ERR_INVALID; }
+    const size_t bytes = (size_t)3 * p->nx * p->ny * sizeof(float);
+    void* d_out = nullptr;
+    if (!hip_ok(hipMalloc(&d_out, bytes), "hipMalloc(frame)")) return PT_ERR_OOM;
+    int rc = pt_render_device(sc, p, d_out, nullptr);
+    if (rc == PT_OK && !hip_ok(hipStreamSynchronize(nullptr), "render (synchronize)")) rc = PT_ERR_HIP;
+    if (rc == PT_OK && !hip_ok(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy(frame)")) rc = PT_ERR_HIP;
+    (void)hipFree(d_out);
+    return rc;
+}
+
+extern "C" int pt_render_stats(PtScene* sc, PtRenderStats* stats)
+{
+    if (!sc || !stats) { pt::set_error("pt_render_stats: null argument"); return PT_ERR_INVALID; }
+    if (!sc->have_timing) { pt::set_error("pt_render_stats: no render has run on this scene"); return PT_ERR_INVALID; }
+    if (!hip_ok(hipEventSynchronize(sc->ev_end), "hipEventSynchronize")) return PT_ERR_HIP;
+    float k = 0, tot = 0;
+    if (!hip_ok(hipEventElapsedTime(&k, sc->ev_k0, sc->ev_k1), "hipEventElapsedTime")) return PT_ERR_HIP;
+    if (!hip_ok(hipEventElapsedTime(&tot, sc->ev_begin, sc->ev_end), "hipEventElapsedTime")) return PT_ERR_HIP;
+    sc->last.kernel_ms = k;
+    sc->last.total_ms = tot;
+    *stats = sc->last;
+    return PT_OK;
+}
+
+extern "C" int pt_trace_closest(PtScene* sc, const PtRay* rays, size_t n, int32_t* prim_id, float* t)
+{
+    if (!sc || (n && (!rays || !prim_id || !t))) { pt::set_error("pt_trace_closest: null argument"); return PT_ERR_INVALID; }
+    if (n == 0) return PT_OK;
+    PtRay* d_rays = nullptr; int32_t* d_ids = nullptr; float* d_t = nullptr;
+    int rc = PT_OK;
+    if (!hip_ok(hipMalloc((void**)&d_rays, n * sizeof(PtRay)), "hipMalloc(rays)") ||
+        !hip_ok(hipMalloc((void**)&d_ids, n * sizeof(int32_t)), "hipMalloc(ids)") ||
+        !hip_ok(hipMalloc((void**)&d_t, n * sizeof(float)), "hipMalloc(t)")) rc = PT_ERR_OOM;
+    if (rc == PT_OK && !hip_ok(hipMemcpy(d_rays, rays, n * sizeof(PtRay), hipMemcpyHostToDevice), "hipMemcpy(rays)")) rc = PT_ERR_HIP;
+    if (rc == PT_OK) {
+        launch_trace(sc->variant, sc->view, d_rays, n, d_ids, d_t, nullptr);
+        if (!hip_ok(hipGetLastError(), "trace kernel launch") || !hip_ok(hipStreamSynchronize(nullptr), "trace (synchronize)")) rc = PT_ERR_HIP;
+    }
+    if (rc == PT_OK && (!hip_ok(hipMemcpy(prim_id, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy(ids)") ||
+                        !hip_ok(hipMemcpy(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(t)"))) rc = PT_ERR_HIP;
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_ids) (void)hipFree(d_ids);
+    if (d_t) (void)hipFree(d_t);
+    return rc;
+}
+
+extern "C" int pt_scene_lbvh_nodes(PtScene* sc, void* nodes, size_t capacity_bytes)
+{
+    if (!sc) { pt::set_error("pt_scene_lbvh_nodes: null scene"); return PT_ERR_INVALID; }
+    if (!sc->view.lbvh) return 0;
+    const size_t bytes = (size_t)sc->lbvh_nodes * sizeof(LbvhNode);
+    if (nodes) {
+        if (capacity_bytes < bytes) { pt::set_error("pt_scene_lbvh_nodes: buffer too small"); return PT_ERR_INVALID; }
+        if (!hip_ok(hipMemcpy(nodes, sc->view.lbvh, bytes, hipMemcpyDeviceToHost), "hipMemcpy(lbvh)")) return PT_ERR_HIP;
+    }
+    return sc->lbvh_nodes;
+}

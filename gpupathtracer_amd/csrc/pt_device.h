@@ -1,0 +1,918 @@
+// Device-side radiance stages for gfx950: camera, closest hit over tagged SoA geometry,
+// hit completion, materials, light/cosine mixture sampling, textures, noise, media.
+//
+// The reference runs these as virtual calls on device-`new`ed objects
+// (include/ptHitable.h:51-65, include/ptMaterial.h:48-61); here they are switch-free where
+// the scene allows it: every stage is a template over a feature mask, and a scene only pays
+// for the primitive / material / texture kinds it contains.
+//
+// Arithmetic contract: every float expression is evaluated in the reference's order with
+// one rounding per operation (build with -ffp-contract=off; HIP's default correctly-rounded
+// fp32 divide and sqrt).  Where the reference's C++ leaves an order unspecified the order
+// g++ picks is used (z before x in XZRectangle::random).
+#ifndef PT_DEVICE_H
+#define PT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#include "../../include/ptcore.h"
+
+namespace ptd {
+
+// ---- feature mask ---------------------------------------------------------------------
+enum : uint32_t {
+    F_SPHERE     = 1u << 0,
+    F_MSPHERE    = 1u << 1,
+    F_RECT       = 1u << 2,
+    F_BOX        = 1u << 3,
+    F_TRIANGLE   = 1u << 4,
+    F_XFORM      = 1u << 5,
+    F_MEDIUM     = 1u << 6,
+    F_REFBVH     = 1u << 7,
+    F_LBVH       = 1u << 8,
+    F_LIGHTS     = 1u << 9,    // a light shape is present (mixture sampling)
+    F_LIGHT_MISC = 1u << 10,   // light shapes other than one bare XZ rectangle
+    F_METAL      = 1u << 11,
+    F_DIELECTRIC = 1u << 12,
+    F_ISOTROPIC  = 1u << 13,
+    F_CHECKER    = 1u << 14,
+    F_NOISE      = 1u << 15,
+    F_IMAGE      = 1u << 16,
+    F_SKY        = 1u << 17,
+    F_ALL        = (1u << 18) - 1
+};
+
+constexpr float PI_F = 3.141592654f;   // CUDART_PI_F
+
+// 64-byte LBVH node: both children's boxes plus two links (>= 0 inner node, < 0 ~shape).
+struct LbvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad0, pad1;
+};
+
+struct SceneView {
+    const PtShape*    shapes;
+    const PtTriUV*    tri_uvs;
+    const PtXform*    xforms;
+    const PtMaterial* materials;
+    const PtTexture*  textures;
+    const uint8_t*    texels;
+    const PtMedium*   media;
+    const PtBvhNode*  bvh_nodes;
+    const PtBvh*      bvhs;
+    const PtObject*   world;
+    const int32_t*    lights;
+    const LbvhNode*   lbvh;
+    int32_t n_world, n_lights, lights_is_list, ambient_type;
+    int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
+    int32_t lbvh_cull;          // 1: prune by distance (no triangles in the tree)
+    float   ambient[3];
+    float   camera[24];
+};
+
+// ---- small vector type ------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ float len(V3 a) { return sqrtf(sqlen(a)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 unit(V3 a) { return a / len(a); }
+
+struct Ray { V3 o, d; float time; };
+__device__ __forceinline__ V3 at(const Ray& r, float t) { return r.o + t * r.d; }
+
+// ---- PCG-XSH-RR 64/32 (include/ptRNG.h:96-134) ----------------------------------------------
+struct Pcg {
+    uint64_t state, inc;
+    __device__ __forceinline__ uint32_t next_u32()
+    {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+    }
+    __device__ __forceinline__ void seed(uint64_t s)
+    {
+        state = 0u;
+        inc = (s << 1u) | 1u;
+        next_u32();
+        state += 0x853c49e6748fea9bULL;
+        next_u32();
+    }
+    __device__ __forceinline__ float rand()
+    {
+        return fminf(0.99999994f, (float)next_u32() * 2.3283064365386963e-10f);
+    }
+};
+
+// ---- sampling helpers (include/ptRNG.h:137-172) ---------------------------------------------
+__device__ __forceinline__ V3 random_in_unit_sphere(Pcg& g)
+{
+    const float phi = g.rand() * 2 * PI_F;
+    const float z = 1 - 2 * g.rand();
+    const float r = sqrtf(fmaxf(0.0f, 1 - z * z));
+    return mk(r * cosf(phi), r * sinf(phi), z);
+}
+__device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
+{
+    const float r = sqrtf(g.rand());
+    const float theta = g.rand() * 2 * PI_F;
+    return mk(r * cosf(theta), r * sinf(theta), 0.0f);
+}
+__device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
+{
+    float r1 = g.rand();
+    float r2 = g.rand();
+    float z = sqrtf(1 - r2);
+    float phi = 2 * PI_F * r1;
+    float x = cosf(phi) * 2 * sqrtf(r2);
+    float y = sinf(phi) * 2 * sqrtf(r2);
+    return mk(x, y, z);
+}
+__device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqrd, Pcg& g)
+{
+    float r1 = g.rand();
+    float r2 = g.rand();
+    float z = 1 + r2 * (sqrtf(1 - radius * radius / dist_sqrd) - 1);
+    float phi = 2 * PI_F * r1;
+    float x = cosf(phi) * sqrtf(1 - z * z);
+    float y = sinf(phi) * sqrtf(1 - z * z);
+    return mk(x, y, z);
+}
+
+// ---- orthonormal basis (include/ptONB.h:27-39) ------------------------------------------------
+struct Onb { V3 u, v, w; };
+__device__ __forceinline__ Onb onb_from_w(V3 n)
+{
+    Onb b;
+    b.w = unit(n);
+    V3 a = (fabsf(b.w.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
+    b.v = unit(cross(b.w, a));
+    b.u = cross(b.w, b.v);
+    return b;
+}
+__device__ __forceinline__ V3 onb_local(const Onb& b, V3 a) { return a.x * b.u + a.y * b.v + a.z * b.w; }
+
+// ---- camera (include/ptCamera.h:28-34) ---------------------------------------------------------
+__device__ __forceinline__ Ray camera_ray(const SceneView& sv, float s, float t, Pcg& g)
+{
+    const float* c = sv.camera;
+    const V3 origin = mk(c[0], c[1], c[2]), llc = mk(c[3], c[4], c[5]);
+    const V3 horiz = mk(c[6], c[7], c[8]), vert = mk(c[9], c[10], c[11]);
+    const V3 cu = mk(c[12], c[13], c[14]), cv = mk(c[15], c[16], c[17]);
+    V3 rd = c[23] * random_in_unit_disk(g);
+    V3 offset = cu * rd.x + cv * rd.y;
+    float time = c[21] + g.rand() * (c[22] - c[21]);
+    Ray r;
+    r.o = origin + offset;
+    r.d = llc + s * horiz + t * vert - origin - offset;
+    r.time = time;
+    return r;
+}
+
+// ---- leaf intersection: parametric distance only -------------------------------------------------
+// A candidate is (t, face).  face: BOX -> which of its six rectangles won.
+
+// Sphere::hit (src/ptSphere.cu:11-40): both roots, strict range on both ends.
+__device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray& r, float tmin, float tmax, float& t)
+{
+    V3 oc = r.o - center;
+    float a = dot(r.d, r.d);
+    float b = dot(oc, r.d);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = b * b - a * c;
+    if (disc > 0) {
+        float sq = sqrtf(disc);
+        float temp = (-b - sq) / a;
+        if (temp < tmax && temp > tmin) { t = temp; return true; }
+        temp = (-b + sq) / a;
+        if (temp < tmax && temp > tmin) { t = temp; return true; }
+    }
+    return false;
+}
+// MovingSphere::center (include/ptSphere.h:106-109)
+__device__ __forceinline__ V3 msphere_center(const float* q, float time)
+{
+    V3 c0 = mk(q[0], q[1], q[2]), c1 = mk(q[3], q[4], q[5]);
+    return c0 + ((time - q[6]) / (q[7] - q[6])) * (c1 - c0);
+}
+// X?Rectangle::hit (src/ptRectangle.cu:12-28,66-82,120-136): inclusive range.
+// (ok,dk) plane axis, (oa,da) and (ob,db) the two in-plane axes.
+__device__ __forceinline__ bool rect_t(float ok, float dk, float oa, float da, float ob, float db,
+                                       float a0, float a1, float b0, float b1, float k,
+                                       float t0, float t1, float& t)
+{
+    float tt = (k - ok) / dk;
+    if (tt < t0 || tt > t1) return false;
+    float a = oa + tt * da;
+    float b = ob + tt * db;
+    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    t = tt;
+    return true;
+}
+// Box = list of six rectangles searched with a shrinking upper bound
+// (include/ptRectangle.h:199-217, src/ptHitableList.cu:12-27): a later face wins ties.
+__device__ __forceinline__ bool box_t(const float* q, const Ray& r, float t0, float t1, float& t, int& face)
+{
+    const float x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
+    bool any = false;
+    float closest = t1, tt;
+    if (rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z1, t0, closest, tt)) { any = true; closest = tt; face = 0; }
+    if (rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z0, t0, closest, tt)) { any = true; closest = tt; face = 1; }
+    if (rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y1, t0, closest, tt)) { any = true; closest = tt; face = 2; }
+    if (rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y0, t0, closest, tt)) { any = true; closest = tt; face = 3; }
+    if (rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x1, t0, closest, tt)) { any = true; closest = tt; face = 4; }
+    if (rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x0, t0, closest, tt)) { any = true; closest = tt; face = 5; }
+    t = closest;
+    return any;
+}
+// Triangle::hit (src/ptTriangle.cu:28-72): Moller-Trumbore with back-face cull; the value
+// compared against the range and reported is dot(edge2,qvec) WITHOUT the 1/det factor.
+__device__ __forceinline__ bool triangle_t(const float* q, const Ray& r, float t_min, float t_max, float& t)
+{
+    V3 v0 = mk(q[0], q[1], q[2]), v1 = mk(q[3], q[4], q[5]), v2 = mk(q[6], q[7], q[8]);
+    V3 edge1 = v1 - v0;
+    V3 edge2 = v2 - v0;
+    V3 pvec = cross(r.d, edge2);
+    float det = dot(edge1, pvec);
+    if (det < 0.0001f) return false;
+    V3 tvec = r.o - v0;
+    float u = dot(tvec, pvec);
+    if (u < 0 || u > det) return false;
+    V3 qvec = cross(tvec, edge1);
+    float v = dot(r.d, qvec);
+    if (v < 0 || u + v > det) return false;
+    float tt = dot(edge2, qvec);
+    if (tt < t_min || tt > t_max) return false;
+    t = tt;
+    return true;
+}
+
+// Translate / RotateY applied to the ray, outermost first (include/ptRectangle.h:272-281,368-379).
+__device__ __forceinline__ Ray to_local(const SceneView& sv, int first, int count, Ray r)
+{
+    for (int k = 0; k < count; k++) {
+        const PtXform x = sv.xforms[first + k];
+        if (x.type == PT_XFORM_TRANSLATE) {
+            r.o = r.o - mk(x.v[0], x.v[1], x.v[2]);
+        } else {
+            const float sinT = x.v[0], cosT = x.v[1];
+            float ox = cosT * r.o.x - sinT * r.o.z;
+            float oz = sinT * r.o.x + cosT * r.o.z;
+            float dx = cosT * r.d.x - sinT * r.d.z;
+            float dz = sinT * r.d.x + cosT * r.d.z;
+            r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+        }
+    }
+    return r;
+}
+// Undo the wrappers on a hit point and normal, innermost first (ptRectangle.h:277,382-389).
+__device__ __forceinline__ void to_world(const SceneView& sv, int first, int count, V3& p, V3& n)
+{
+    for (int k = count - 1; k >= 0; k--) {
+        const PtXform x = sv.xforms[first + k];
+        if (x.type == PT_XFORM_TRANSLATE) {
+            p = p + mk(x.v[0], x.v[1], x.v[2]);
+        } else {
+            const float sinT = x.v[0], cosT = x.v[1];
+            float px = cosT * p.x + sinT * p.z;
+            float pz = -sinT * p.x + cosT * p.z;
+            float nx = cosT * n.x + sinT * n.z;
+            float nz = -sinT * n.x + cosT * n.z;
+            p.x = px; p.z = pz; n.x = nx; n.z = nz;
+        }
+    }
+}
+
+// One leaf shape against a ray: true when shape.hit(ray, tmin, tmax) would be.
+template <uint32_t F>
+__device__ __forceinline__ bool shape_t(const SceneView& sv, int index, const Ray& ray, float tmin, float tmax,
+                                        float& t, int& face)
+{
+    const PtShape* s = &sv.shapes[index];
+    const int type = s->type;
+    Ray r = ray;
+    if (F & F_XFORM) {
+        const int nx = s->xform_count;
+        if (nx > 0) r = to_local(sv, s->xform_first, nx, ray);
+    }
+    face = 0;
+    if ((F & F_SPHERE) && type == PT_SHAPE_SPHERE)
+        return sphere_t(mk(s->p[0], s->p[1], s->p[2]), s->p[3], r, tmin, tmax, t);
+    if ((F & F_MSPHERE) && type == PT_SHAPE_MOVING_SPHERE)
+        return sphere_t(msphere_center(s->p, r.time), s->p[8], r, tmin, tmax, t);
+    if (F & F_RECT) {
+        if (type == PT_SHAPE_RECT_XY)
+            return rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, tmax, t);
+        if (type == PT_SHAPE_RECT_XZ)
+            return rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, tmax, t);
+        if (type == PT_SHAPE_RECT_YZ)
+            return rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, tmax, t);
+    }
+    if ((F & F_BOX) && type == PT_SHAPE_BOX) return box_t(s->p, r, tmin, tmax, t, face);
+    if ((F & F_TRIANGLE) && type == PT_SHAPE_TRIANGLE) return triangle_t(s->p, r, tmin, tmax, t);
+    return false;
+}
+
+// ---- closest hit over the world ---------------------------------------------------------------------
+struct Hit {
+    float t;
+    int32_t id;      // shape index, PT_ID_MEDIUM_BASE + medium, or PT_ID_MISS
+    int32_t face;
+    // The reference's Sphere::hit leaves rec.uv untouched, so a plain sphere reports the uv of
+    // the last accepted uv-writing hit earlier in the same list walk (src/ptHitableList.cu:14-24).
+    // Only image textures read uv; uv_id/uv_face/uv_t remember that earlier hit.
+    int32_t uv_id, uv_face;
+    float uv_t;
+};
+
+// AABB::hit (include/ptAABB.h:30-48)
+__device__ __forceinline__ bool aabb_hit(const float* bmin, const float* bmax, const Ray& r, float tmin, float tmax)
+{
+    {
+        const float invD = 1 / r.d.x;
+        float t0 = (bmin[0] - r.o.x) * invD, t1 = (bmax[0] - r.o.x) * invD;
+        if (invD < 0) { float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    {
+        const float invD = 1 / r.d.y;
+        float t0 = (bmin[1] - r.o.y) * invD, t1 = (bmax[1] - r.o.y) * invD;
+        if (invD < 0) { float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    {
+        const float invD = 1 / r.d.z;
+        float t0 = (bmin[2] - r.o.z) * invD, t1 = (bmax[2] - r.o.z) * invD;
+        if (invD < 0) { float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool writes_uv(int shape_type)
+{
+    return shape_type != PT_SHAPE_SPHERE;
+}
+
+// BVH::hit (src/ptBVH.cu:45-74) without recursion.  The reference visits both children of every
+// node whose box the ray meets within the caller's [tmin,tmax] (the range never shrinks inside
+// the tree) and keeps the left result only when it is strictly nearer; the winner over a subtree
+// is therefore the right-most leaf among those with the smallest t.  A left-to-right walk that
+// lets a later leaf replace the best one unless the best is strictly nearer gives the same leaf.
+constexpr int REFBVH_STACK = 48;
+template <uint32_t F>
+__device__ __forceinline__ bool refbvh_t(const SceneView& sv, int bvh_index, const Ray& ray, float tmin, float tmax,
+                                         float& t_out, int& id_out, int& face_out)
+{
+    const PtBvh b = sv.bvhs[bvh_index];
+    Ray r = ray;
+    if (F & F_XFORM) { if (b.xform_count > 0) r = to_local(sv, b.xform_first, b.xform_count, ray); }
+    int stack[REFBVH_STACK];
+    int sp = 0;
+    int cur = b.root;
+    bool any = false;
+    float best = 0.0f;
+    while (true) {
+        if (cur >= 0) {
+            const PtBvhNode* n = &sv.bvh_nodes[cur];
+            if (aabb_hit(n->bmin, n->bmax, r, tmin, tmax)) {
+                if (sp < REFBVH_STACK) stack[sp++] = n->right;
+                cur = n->left;
+                continue;
+            }
+        } else {
+            float t; int face;
+            if (shape_t<F>(sv, ~cur, r, tmin, tmax, t, face)) {
+                if (!any || !(best < t)) { any = true; best = t; id_out = ~cur; face_out = face; }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    t_out = best;
+    return any;
+}
+
+// ConstantMedium::hit (include/ptMedium.h:31-55).  Draws one random number whenever the ray
+// crosses the boundary twice and the clipped interval is not inverted.
+template <uint32_t F>
+__device__ __forceinline__ bool medium_t(const SceneView& sv, int m, const Ray& r, float t0, float t1, float& t, Pcg& g)
+{
+    const PtMedium med = sv.media[m];
+    float ta, tb; int face;
+    if (shape_t<F>(sv, med.boundary, r, -FLT_MAX, FLT_MAX, ta, face)) {
+        if (shape_t<F>(sv, med.boundary, r, (float)((double)ta + 0.0001), FLT_MAX, tb, face)) {
+            if (ta < t0) ta = t0;
+            if (tb > t1) tb = t1;
+            if (ta > tb) return false;
+            if (ta < 0) ta = 0;
+            float dist_inside = (tb - ta) * len(r.d);
+            float hit_dist = -(1 / med.density) * logf(g.rand());
+            if (hit_dist < dist_inside) {
+                t = ta + hit_dist / len(r.d);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// Tie rule of an in-order list walk, usable in any visiting order.  Spheres accept
+// tmin < t < closest (an earlier entry keeps an exact tie), rectangles, boxes and triangles accept
+// t <= closest (a later entry takes it): src/ptSphere.cu:21,30, src/ptRectangle.cu:15,
+// src/ptTriangle.cu:66.  Between two candidates with equal t the later one wins iff it is of the
+// inclusive kind.
+__device__ __forceinline__ bool inclusive_kind(int shape_type)
+{
+    return shape_type != PT_SHAPE_SPHERE && shape_type != PT_SHAPE_MOVING_SPHERE;
+}
+__device__ __forceinline__ bool list_order_better(const SceneView& sv, float t, int id, float best_t, int best_id)
+{
+    if (t < best_t) return true;
+    if (t > best_t) return false;
+    if (id > best_id) return inclusive_kind(sv.shapes[id].type);
+    return !inclusive_kind(sv.shapes[best_id].type);
+}
+
+// Library-built LBVH over the world list: any-order stack walk with the tie rule above.
+// The first LBVH_LDS_STACK pending nodes of a lane live in LDS (one 4-byte column per lane, stride
+// 64 so a wave's pushes hit 64 different banks); deeper entries spill to private memory.
+constexpr int LBVH_LDS_STACK = 24;
+constexpr int LBVH_STACK = 64;
+__device__ __forceinline__ bool slab(const float* bmin, const float* bmax, V3 o, V3 inv, float tmin, float tmax, float& tnear)
+{
+    float tx0 = (bmin[0] - o.x) * inv.x, tx1 = (bmax[0] - o.x) * inv.x;
+    float ty0 = (bmin[1] - o.y) * inv.y, ty1 = (bmax[1] - o.y) * inv.y;
+    float tz0 = (bmin[2] - o.z) * inv.z, tz1 = (bmax[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    tnear = tn;
+    // widened by a few ulps so a leaf the in-order walk would accept is never pruned
+    return tn * 0.9999990f <= tf * 1.0000010f;
+}
+template <uint32_t F>
+__device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float tmin, float tmax,
+                                       float& t_out, int& id_out, int& face_out, int* stack)
+{
+    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const bool cull = sv.lbvh_cull != 0;
+    int spill[LBVH_STACK - LBVH_LDS_STACK];
+    int sp = 0;
+    int cur = sv.lbvh_root;
+    bool any = false;
+    float best = tmax;
+    int best_id = -1, best_face = 0;
+    while (true) {
+        if (cur >= 0) {
+            const LbvhNode* n = &sv.lbvh[cur];
+            const float lim = cull ? best : tmax;
+            float tl, tr;
+            bool hl = slab(n->lmin, n->lmax, r.o, inv, tmin, lim, tl);
+            bool hr = slab(n->rmin, n->rmax, r.o, inv, tmin, lim, tr);
+            int cl = n->left, cr = n->right;
+            if (hl && hr) {
+                if (tr < tl) { int tmp = cl; cl = cr; cr = tmp; }
+                if (sp < LBVH_LDS_STACK) stack[sp * 64] = cr;
+                else if (sp < LBVH_STACK) spill[sp - LBVH_LDS_STACK] = cr;
+                sp++;
+                cur = cl;
+                continue;
+            } else if (hl) { cur = cl; continue; }
+            else if (hr) { cur = cr; continue; }
+        } else {
+            const int id = ~cur;
+            float t; int face;
+            if (shape_t<F>(sv, id, r, tmin, tmax, t, face)) {
+                if (!any || list_order_better(sv, t, id, best, best_id)) { any = true; best = t; best_id = id; best_face = face; }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = (sp < LBVH_LDS_STACK) ? stack[sp * 64] : spill[sp - LBVH_LDS_STACK];
+    }
+    t_out = best; id_out = best_id; face_out = best_face;
+    return any;
+}
+
+// world->hit(ray, tmin, tmax) (src/ptHitableList.cu:12-27).
+// lbvh_stack: this lane's column of the LDS traversal stack (stride 64 ints), or nullptr.
+template <uint32_t F>
+__device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, float tmin, float tmax, Hit& h, Pcg& g,
+                                          int* lbvh_stack)
+{
+    h.id = PT_ID_MISS; h.face = 0; h.t = tmax; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
+    if (F & F_LBVH) {
+        float t; int id, face;
+        if (lbvh_t<F>(sv, r, tmin, tmax, t, id, face, lbvh_stack)) { h.t = t; h.id = id; h.face = face; return true; }
+        return false;
+    }
+    bool any = false;
+    float closest = tmax;
+    const int n = sv.n_world;
+    for (int i = 0; i < n; i++) {
+        const PtObject ob = sv.world[i];
+        float t; int id = ob.index, face = 0;
+        bool hit = false;
+        if (!(F & (F_MEDIUM | F_REFBVH)) || ob.type == PT_OBJ_SHAPE) {
+            hit = shape_t<F>(sv, ob.index, r, tmin, closest, t, face);
+        } else if ((F & F_MEDIUM) && ob.type == PT_OBJ_MEDIUM) {
+            hit = medium_t<F>(sv, ob.index, r, tmin, closest, t, g);
+            id = PT_ID_MEDIUM_BASE + ob.index;
+        } else if ((F & F_REFBVH) && ob.type == PT_OBJ_BVH) {
+            hit = refbvh_t<F>(sv, ob.index, r, tmin, closest, t, id, face);
+        }
+        if (hit) {
+            any = true; closest = t; h.t = t; h.id = id; h.face = face;
+            if (F & F_IMAGE) {
+                if (id < PT_ID_MEDIUM_BASE && writes_uv(sv.shapes[id].type)) { h.uv_id = id; h.uv_face = face; h.uv_t = t; }
+            }
+        }
+    }
+    return any;
+}
+
+// ---- hit completion: the HitRecord fields the shaders read --------------------------------------------
+struct Surface { V3 p, n; float u, v; int32_t mat; };
+
+__device__ __forceinline__ void get_uv(V3 p, float& u, float& v)     // include/ptSphere.h:22-28
+{
+    float phi = atan2f(p.z, p.x);
+    float theta = asinf(p.y);
+    u = 1 - (phi + PI_F) / (2 * PI_F);
+    v = (theta + PI_F / 2) / PI_F;
+}
+
+// uv a uv-writing leaf records for a hit at parameter t (object-space ray r).
+template <uint32_t F>
+__device__ __forceinline__ void leaf_uv(const SceneView& sv, const PtShape* s, const Ray& r, float t, int face, float& u, float& v)
+{
+    const int type = s->type;
+    u = 0.0f; v = 0.0f;
+    int rtype = type;
+    float a0 = s->p[0], a1 = s->p[1], b0 = s->p[2], b1 = s->p[3];
+    if ((F & F_BOX) && type == PT_SHAPE_BOX) {
+        const float* q = s->p;
+        if (face < 2) { rtype = PT_SHAPE_RECT_XY; a0 = q[0]; a1 = q[3]; b0 = q[1]; b1 = q[4]; }
+        else if (face < 4) { rtype = PT_SHAPE_RECT_XZ; a0 = q[0]; a1 = q[3]; b0 = q[2]; b1 = q[5]; }
+        else { rtype = PT_SHAPE_RECT_YZ; a0 = q[1]; a1 = q[4]; b0 = q[2]; b1 = q[5]; }
+    }
+    if ((F & (F_RECT | F_BOX)) && (rtype == PT_SHAPE_RECT_XY || rtype == PT_SHAPE_RECT_XZ || rtype == PT_SHAPE_RECT_YZ)) {
+        float oa, da, ob, db;
+        if (rtype == PT_SHAPE_RECT_XY) { oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+        else if (rtype == PT_SHAPE_RECT_XZ) { oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+        else { oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+        float a = oa + t * da, b = ob + t * db;
+        u = (a - a0) / (a1 - a0);
+        v = (b - b0) / (b1 - b0);
+        return;
+    }
+    if ((F & F_MSPHERE) && type == PT_SHAPE_MOVING_SPHERE) { get_uv(at(r, t), u, v); return; }
+    if ((F & F_TRIANGLE) && type == PT_SHAPE_TRIANGLE) {
+        const float* q = s->p;
+        V3 v0 = mk(q[0], q[1], q[2]), v1 = mk(q[3], q[4], q[5]), v2 = mk(q[6], q[7], q[8]);
+        V3 edge1 = v1 - v0, edge2 = v2 - v0;
+        V3 pvec = cross(r.d, edge2);
+        float det = dot(edge1, pvec);
+        V3 tvec = r.o - v0;
+        float bu = dot(tvec, pvec);
+        V3 qvec = cross(tvec, edge1);
+        float bv = dot(r.d, qvec);
+        const float inv_det = 1 / det;
+        bu *= inv_det; bv *= inv_det;
+        float b0f = (float)(1.0 - (double)bu - (double)bv);
+        if (s->tri_uv >= 0) {
+            const PtTriUV tu = sv.tri_uvs[s->tri_uv];
+            u = tu.uv0[0] * b0f + tu.uv1[0] * bu + tu.uv2[0] * bv;
+            v = tu.uv0[1] * b0f + tu.uv1[1] * bu + tu.uv2[1] * bv;
+        } else {
+            u = 0.0f * b0f + 0.0f * bu + 0.0f * bv;
+            v = u;
+        }
+    }
+}
+
+template <uint32_t F>
+__device__ __forceinline__ Surface complete_hit(const SceneView& sv, const Ray& ray, const Hit& h)
+{
+    Surface sf;
+    sf.u = 0.0f; sf.v = 0.0f;
+    if ((F & F_MEDIUM) && h.id >= PT_ID_MEDIUM_BASE) {            // include/ptMedium.h:46-49
+        sf.p = at(ray, h.t);
+        sf.n = mk(1, 0, 0);
+        sf.mat = sv.media[h.id - PT_ID_MEDIUM_BASE].material;
+        return sf;
+    }
+    const PtShape* s = &sv.shapes[h.id];
+    const int type = s->type;
+    Ray r = ray;
+    const int nxf = (F & F_XFORM) ? s->xform_count : 0;
+    if (F & F_XFORM) { if (nxf > 0) r = to_local(sv, s->xform_first, nxf, ray); }
+    sf.mat = s->material;
+    sf.p = at(r, h.t);
+    sf.n = mk(0, 0, 0);
+    if ((F & F_SPHERE) && type == PT_SHAPE_SPHERE) {
+        sf.n = (sf.p - mk(s->p[0], s->p[1], s->p[2])) / s->p[3];
+    } else if ((F & F_MSPHERE) && type == PT_SHAPE_MOVING_SPHERE) {
+        sf.n = (sf.p - msphere_center(s->p, r.time)) / s->p[8];
+    } else if ((F & F_RECT) && type == PT_SHAPE_RECT_XY) { sf.n = mk(0, 0, 1); }
+    else if ((F & F_RECT) && type == PT_SHAPE_RECT_XZ) { sf.n = mk(0, 1, 0); }
+    else if ((F & F_RECT) && type == PT_SHAPE_RECT_YZ) { sf.n = mk(1, 0, 0); }
+    else if ((F & F_BOX) && type == PT_SHAPE_BOX) {
+        const int f = h.face;
+        sf.n = (f < 2) ? mk(0, 0, 1) : (f < 4) ? mk(0, 1, 0) : mk(1, 0, 0);
+        if (f & 1) sf.n = -sf.n;                                   // the odd faces sit under FlipNormals
+    } else if ((F & F_TRIANGLE) && type == PT_SHAPE_TRIANGLE) {    // src/ptTriangle.cu:68-76
+        const float* q = s->p;
+        V3 v0 = mk(q[0], q[1], q[2]), v1 = mk(q[3], q[4], q[5]), v2 = mk(q[6], q[7], q[8]);
+        V3 edge1 = v1 - v0, edge2 = v2 - v0;
+        V3 pvec = cross(r.d, edge2);
+        float det = dot(edge1, pvec);
+        V3 tvec = r.o - v0;
+        float bu = dot(tvec, pvec);
+        V3 qvec = cross(tvec, edge1);
+        float bv = dot(r.d, qvec);
+        const float inv_det = 1 / det;
+        bu *= inv_det; bv *= inv_det;
+        sf.p = (1 - bu - bv) * v0 + bu * v1 + bv * v2;
+        V3 nn = cross(edge1, edge2);
+        float k = 1 / len(nn);
+        sf.n = mk(nn.x * k, nn.y * k, nn.z * k);
+    }
+    if (F & F_IMAGE) {
+        // uv is read by image textures only
+        if (writes_uv(type)) leaf_uv<F>(sv, s, r, h.t, h.face, sf.u, sf.v);
+        else if (h.uv_id >= 0) {
+            const PtShape* us = &sv.shapes[h.uv_id];
+            Ray ur = ray;
+            if (F & F_XFORM) { if (us->xform_count > 0) ur = to_local(sv, us->xform_first, us->xform_count, ray); }
+            leaf_uv<F>(sv, us, ur, h.uv_t, h.uv_face, sf.u, sf.v);
+        }
+    }
+    if (F & F_XFORM) { if (nxf > 0) to_world(sv, s->xform_first, nxf, sf.p, sf.n); }
+    if (s->flags & PT_FLIP_NORMAL) sf.n = -sf.n;                   // include/ptRectangle.h:148-156
+    return sf;
+}
+
+// ---- Perlin noise (src/ptNoise.cu) --------------------------------------------------------------------
+// Ken Perlin's 2002 reference permutation (src/ptNoise.cu:47-112 holds it twice over).
+__device__ __constant__ unsigned char g_perm[256] = {
+    151,160,137,91,90,15,131,13,201,95,96,53,194,233,7,225,140,36,103,30,69,142,8,99,37,240,21,10,23,
+    190,6,148,247,120,234,75,0,26,197,62,94,252,219,203,117,35,11,32,57,177,33,88,237,149,56,87,174,
+    20,125,136,171,168,68,175,74,165,71,134,139,48,27,166,77,146,158,231,83,111,229,122,60,211,133,
+    230,220,105,92,41,55,46,245,40,244,102,143,54,65,25,63,161,1,216,80,73,209,76,132,187,208,89,18,
+    169,200,196,135,130,116,188,159,86,164,100,109,198,173,186,3,64,52,217,226,250,124,123,5,202,38,
+    147,118,126,255,82,85,212,207,206,59,227,47,16,58,17,182,189,28,42,223,183,170,213,119,248,152,
+    2,44,154,163,70,221,153,101,155,167,43,172,9,129,22,39,253,19,98,108,110,79,113,224,232,178,185,
+    112,104,218,246,97,228,251,34,242,193,238,210,144,12,191,179,162,241,81,51,145,235,249,14,239,
+    107,49,192,214,31,181,199,106,157,184,84,204,176,115,121,50,45,127,4,150,254,138,236,205,93,222,
+    114,67,29,24,72,243,141,128,195,78,66,215,61,156,180
+};
+__device__ __forceinline__ int perm(int i) { return g_perm[i & 255]; }
+__device__ __forceinline__ float fade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }
+__device__ __forceinline__ float lerpf(float t, float a, float b) { return a + t * (b - a); }
+__device__ __forceinline__ float grad(int hash, float x, float y, float z)
+{
+    int h = hash & 15;
+    float u = ((h < 8) || (h == 12) || (h == 13)) ? x : y;
+    float v = ((h < 4) || (h == 12) || (h == 13)) ? y : z;
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+__device__ inline float noise3(V3 p)                                // src/ptNoise.cu:114-140
+{
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    int xi = (int)fx & 255, yi = (int)fy & 255, zi = (int)fz & 255;
+    float x = p.x - fx, y = p.y - fy, z = p.z - fz;
+    float u = fade(x), v = fade(y), w = fade(z);
+    int A = perm(xi) + yi, AA = perm(A) + zi, AB = perm(A + 1) + zi;
+    int B = perm(xi + 1) + yi, BA = perm(B) + zi, BB = perm(B + 1) + zi;
+    return lerpf(w, lerpf(v, lerpf(u, grad(perm(AA), x, y, z), grad(perm(BA), x - 1, y, z)),
+                             lerpf(u, grad(perm(AB), x, y - 1, z), grad(perm(BB), x - 1, y - 1, z))),
+                    lerpf(v, lerpf(u, grad(perm(AA + 1), x, y, z - 1), grad(perm(BA + 1), x - 1, y, z - 1)),
+                             lerpf(u, grad(perm(AB + 1), x, y - 1, z - 1), grad(perm(BB + 1), x - 1, y - 1, z - 1))));
+}
+__device__ inline float turbulence7(V3 p)                           // src/ptNoise.cu:142-154, depth 7
+{
+    float accum = 0, weight = 1;
+    V3 tp = p;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * noise3(tp);
+        weight *= 0.5f;
+        tp = tp * 2.0f;
+    }
+    return fabsf(accum);
+}
+
+// ---- textures (include/ptTexture.h) --------------------------------------------------------------------
+template <uint32_t F>
+__device__ __forceinline__ V3 texture_value(const SceneView& sv, int tex, float u, float v, V3 p)
+{
+    PtTexture t = sv.textures[tex];
+    if (F & F_CHECKER) {
+        // nested checkers resolve iteratively (:90-97)
+        for (int guard = 0; guard < 8 && t.type == PT_TEX_CHECKER; guard++) {
+            float sines = sinf(t.scale * p.x) * sinf(t.scale * p.y) * sinf(t.scale * p.z);
+            t = sv.textures[(sines < 0) ? t.odd : t.even];
+        }
+    }
+    if ((F & F_NOISE) && t.type == PT_TEX_NOISE) {                  // :142-146
+        float n = 0.5f * (1 + sinf(t.scale * p.z + 10 * turbulence7(p)));
+        return mk(n, n, n);
+    }
+    if ((F & F_IMAGE) && t.type == PT_TEX_IMAGE) {                  // :187-199
+        int nx = t.nx, ny = t.ny;
+        int i = (int)(u * nx);
+        int j = (int)((1 - v) * ny - 0.001f);
+        i = max(0, i); j = max(0, j);
+        i = min(i, nx - 1); j = min(j, ny - 1);
+        const uint8_t* d = sv.texels + t.texel_offset + 3 * i + 3 * nx * j;
+        return mk((int)d[0] / 255.0f, (int)d[1] / 255.0f, (int)d[2] / 255.0f);
+    }
+    return mk(t.color[0], t.color[1], t.color[2]);                  // :47-50
+}
+
+// ---- light shapes: pdfValue / random ---------------------------------------------------------------------
+template <uint32_t F>
+__device__ __forceinline__ float light_shape_pdf(const SceneView& sv, int shape, V3 o, V3 v)
+{
+    const PtShape* s = &sv.shapes[shape];
+    Ray r; r.o = o; r.d = v; r.time = 0;
+    if (!(F & F_LIGHT_MISC) || (s->type == PT_SHAPE_RECT_XZ && s->xform_count == 0)) {   // include/ptRectangle.h:77-89
+        float t;
+        if (rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], 0.001f, FLT_MAX, t)) {
+            float area = (s->p[1] - s->p[0]) * (s->p[3] - s->p[2]);
+            float dist_sqrd = t * t * sqlen(v);
+            float cosine = fabsf(dot(v, mk(0, 1, 0)) / len(v));
+            return dist_sqrd / (cosine * area);
+        }
+        return 0;
+    }
+    if (s->type == PT_SHAPE_SPHERE && s->xform_count == 0) {                               // include/ptSphere.h:48-58
+        float t;
+        V3 center = mk(s->p[0], s->p[1], s->p[2]);
+        if (sphere_t(center, s->p[3], r, 0.001f, FLT_MAX, t)) {
+            float cos_theta_max = sqrtf(1 - s->p[3] * s->p[3] / sqlen(center - o));
+            float solid_angle = 2 * PI_F * (1 - cos_theta_max);
+            return 1 / solid_angle;
+        }
+        return 0;
+    }
+    return 0;                                                                              // include/ptHitable.h:58
+}
+template <uint32_t F>
+__device__ __forceinline__ V3 light_shape_random(const SceneView& sv, int shape, V3 o, Pcg& g)
+{
+    const PtShape* s = &sv.shapes[shape];
+    if (!(F & F_LIGHT_MISC) || (s->type == PT_SHAPE_RECT_XZ && s->xform_count == 0)) {   // include/ptRectangle.h:91-95
+        float rz = g.rand();       // g++ evaluates the constructor arguments right to left
+        float rx = g.rand();
+        V3 rp = mk(s->p[0] + rx * (s->p[1] - s->p[0]), s->p[4], s->p[2] + rz * (s->p[3] - s->p[2]));
+        return rp - o;
+    }
+    if (s->type == PT_SHAPE_SPHERE && s->xform_count == 0) {                               // include/ptSphere.h:60-67
+        V3 dir = mk(s->p[0], s->p[1], s->p[2]) - o;
+        float dist_sqrd = sqlen(dir);
+        Onb uvw = onb_from_w(dir);
+        return onb_local(uvw, random_to_unit_sphere(s->p[3], dist_sqrd, g));
+    }
+    return mk(1, 0, 0);                                                                    // include/ptHitable.h:59
+}
+template <uint32_t F>
+__device__ __forceinline__ float lights_pdf(const SceneView& sv, V3 o, V3 v)
+{
+    if (!(F & F_LIGHT_MISC) || !sv.lights_is_list) return light_shape_pdf<F>(sv, sv.lights[0], o, v);
+    float weight = 1 / (float)sv.n_lights;                                                 // include/ptHitableList.h:29-38
+    float sum = 0;
+    for (int i = 0; i < sv.n_lights; i++) sum += weight * light_shape_pdf<F>(sv, sv.lights[i], o, v);
+    return sum;
+}
+template <uint32_t F>
+__device__ __forceinline__ V3 lights_random(const SceneView& sv, V3 o, Pcg& g)
+{
+    if (!(F & F_LIGHT_MISC) || !sv.lights_is_list) return light_shape_random<F>(sv, sv.lights[0], o, g);
+    int index = (int)(g.rand() * sv.n_lights);                                             // include/ptHitableList.h:40-44
+    return light_shape_random<F>(sv, sv.lights[index], o, g);
+}
+
+__device__ __forceinline__ float cosine_pdf_value(const Onb& uvw, V3 dir)                 // include/ptPDF.h:46-53
+{
+    float cosine = dot(unit(dir), uvw.w);
+    return (cosine > 0) ? cosine / PI_F : 0.0f;
+}
+
+__device__ __forceinline__ float schlick(float cs, float ri)                              // include/ptMaterial.h:31-37
+{
+    float r0 = (1 - ri) / (1 + ri);
+    r0 = r0 * r0;
+    return r0 + (1 - r0) * powf(1 - cs, 5.0f);
+}
+
+// ---- one bounce of color() (src/ptMain.cu:101-148) --------------------------------------------------------
+// Returns true when the path continues with `ray` replaced; false when it ended (thr holds its
+// final value).  thr is the running product accumCol.
+template <uint32_t F>
+__device__ __forceinline__ bool shade(const SceneView& sv, Ray& ray, const Hit& h, V3& thr, Pcg& g)
+{
+    const Surface sf = complete_hit<F>(sv, ray, h);
+    const PtMaterial m = sv.materials[sf.mat];
+    if (m.type == PT_MAT_DIFFUSE_LIGHT) {                          // include/ptMaterial.h:262-272
+        V3 emitted = mk(0, 0, 0);
+        if (dot(sf.n, ray.d) < 0) emitted = texture_value<F>(sv, m.texture, sf.u, sf.v, sf.p);
+        thr = thr * emitted;
+        return false;
+    }
+    if ((F & F_METAL) && m.type == PT_MAT_METAL) {                 // include/ptMaterial.h:134-143
+        V3 ud = unit(ray.d);
+        V3 reflected = ud - (2 * dot(ud, sf.n)) * sf.n;
+        V3 fz = m.param * random_in_unit_sphere(g);
+        thr = thr * mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        ray.o = sf.p; ray.d = reflected + fz; ray.time = 0;
+        return true;
+    }
+    if ((F & F_DIELECTRIC) && m.type == PT_MAT_DIELECTRIC) {       // include/ptMaterial.h:184-224
+        const float ref_idx = m.param;
+        const V3 d = ray.d;
+        V3 reflected = d - (2 * dot(d, sf.n)) * sf.n;
+        V3 outward; float ni_over_nt, cosine;
+        const float ddn = dot(d, sf.n);
+        if (ddn > 0.0f) { outward = -sf.n; ni_over_nt = ref_idx; cosine = ref_idx * ddn / len(d); }
+        else { outward = sf.n; ni_over_nt = 1.0f / ref_idx; cosine = -ddn / len(d); }
+        V3 refracted = mk(0, 0, 0);
+        float reflect_prob = 1.0f;
+        {                                                          // refract(), include/ptVector3.h:204-215
+            V3 uv = unit(d);
+            float dt = dot(uv, outward);
+            float disc = 1 - ni_over_nt * ni_over_nt * (1 - dt * dt);
+            if (disc > 0) {
+                refracted = ni_over_nt * (uv - outward * dt) - outward * sqrtf(disc);
+                reflect_prob = schlick(cosine, ref_idx);
+            }
+        }
+        thr = thr * mk(1, 1, 1);
+        ray.o = sf.p; ray.time = 0;
+        ray.d = (g.rand() < reflect_prob) ? reflected : refracted;
+        return true;
+    }
+    // Lambertian / Isotropic: non-specular (include/ptMaterial.h:71-85,317-330)
+    const bool cosine_pdf = !(F & F_ISOTROPIC) || m.type == PT_MAT_LAMBERTIAN;
+    V3 atten = texture_value<F>(sv, m.texture, sf.u, sf.v, sf.p);
+    Onb uvw = onb_from_w(sf.n);
+    V3 dir; float pdf_value;
+    if ((F & F_LIGHTS) && sv.n_lights > 0) {
+        if (g.rand() < 0.5f) dir = lights_random<F>(sv, sf.p, g);   // MixturePdf::generate, include/ptPDF.h:94-100
+        else dir = onb_local(uvw, random_cosine_direction(g));
+        pdf_value = 0.5f * lights_pdf<F>(sv, sf.p, dir) + 0.5f * cosine_pdf_value(uvw, dir);
+    } else {
+        if (cosine_pdf) { dir = onb_local(uvw, random_cosine_direction(g)); pdf_value = cosine_pdf_value(uvw, dir); }
+        else { dir = random_to_unit_sphere(1, 1, g); pdf_value = 1; }   // ConstPdf, include/ptPDF.h:28-39
+    }
+    float spdf;
+    if (cosine_pdf) {
+        float cosine = dot(sf.n, unit(dir));
+        spdf = (cosine < 0) ? 0.0f : cosine / PI_F;
+    } else {
+        spdf = 1.0f / (4.0f * PI_F);
+    }
+    const V3 emitted = mk(0, 0, 0);
+    thr = thr * (emitted + (atten * spdf) / pdf_value);
+    ray.o = sf.p; ray.d = dir;           // time is kept (src/ptMain.cu:123,130)
+    return true;
+}
+
+// Miss shader (src/ptMain.cu:143-148, include/ptAmbientLight.h:48-51,86-91)
+template <uint32_t F>
+__device__ __forceinline__ void shade_miss(const SceneView& sv, const Ray& ray, V3& thr)
+{
+    if ((F & F_SKY) && sv.ambient_type == PT_AMBIENT_SKY) {
+        V3 ud = unit(ray.d);
+        float t = 0.5f * (ud.y + 1);
+        thr = thr * ((1 - t) * mk(1, 1, 1) + t * mk(0.5f, 0.7f, 1.0f));
+    } else if (sv.ambient_type != PT_AMBIENT_NONE) {
+        thr = thr * mk(sv.ambient[0], sv.ambient[1], sv.ambient[2]);
+    }
+}
+
+}  // namespace ptd
+#endif

@@ -1,0 +1,19 @@
+// Morton-code LBVH builder (device side); replaces the reference's BVH::BVH + quickSort
+// (src/ptBVH.cu:15-43, src/ptQuickSort.cu:19-81) for library-accelerated world lists.
+#ifndef PT_LBVH_H
+#define PT_LBVH_H
+
+#include "../../include/ptcore.h"
+
+namespace pt {
+
+// Builds the tree over the shapes named by desc->world (all entries must be PT_OBJ_SHAPE with
+// strictly increasing shape indices).  d_shapes / d_xforms are the already-uploaded device
+// copies.  On success *d_nodes is a hipMalloc'ed array of *n_nodes 64-byte nodes and *root is
+// the root link (>= 0 node index, < 0 ~shape).  Returns a PtError.
+int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,
+               void** d_nodes, int* n_nodes, int* root);
+
+}  // namespace pt
+
+#endif

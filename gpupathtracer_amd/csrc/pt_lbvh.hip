@@ -1,0 +1,375 @@
+// LBVH construction on the device: leaf boxes -> 30-bit Morton codes -> stable LSD radix sort
+// (wave64 ballot ranking) -> Karras radix tree -> bottom-up box fitting -> 64-byte nodes that
+// hold both children's boxes, so one node fetch decides both descents.
+//
+// The reference builds its BVH on the host with a random-axis median split around a Lomuto
+// quicksort (src/ptBVH.cu:15-43, src/ptQuickSort.cu:19-81), quadratic on sorted or tied keys.
+// Only the tree changes here; what a ray hits is still decided by the reference's leaf tests
+// and tie rules, so any conservative tree gives the same answer.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pt_device.h"
+#include "pt_host.h"
+#include "pt_lbvh.h"
+
+using ptd::LbvhNode;
+
+namespace {
+
+struct Box { float mn[3], mx[3]; };
+
+__device__ __forceinline__ void grow(Box& b, float x, float y, float z)
+{
+    b.mn[0] = fminf(b.mn[0], x); b.mn[1] = fminf(b.mn[1], y); b.mn[2] = fminf(b.mn[2], z);
+    b.mx[0] = fmaxf(b.mx[0], x); b.mx[1] = fmaxf(b.mx[1], y); b.mx[2] = fmaxf(b.mx[2], z);
+}
+
+// Conservative world-space box of one shape.  times[] are the ray times that can occur
+// (shutter open, shutter close, and 0 for specular bounces, include/ptMaterial.h:137,217,221).
+__device__ Box leaf_box(const PtShape* shapes, const PtXform* xforms, int index, const float* times)
+{
+    const PtShape s = shapes[index];
+    const float* p = s.p;
+    Box b;
+    for (int a = 0; a < 3; a++) { b.mn[a] = FLT_MAX; b.mx[a] = -FLT_MAX; }
+    float pad = 0.0f;
+    switch (s.type) {
+    case PT_SHAPE_SPHERE:
+        grow(b, p[0] - p[3], p[1] - p[3], p[2] - p[3]);
+        grow(b, p[0] + p[3], p[1] + p[3], p[2] + p[3]);
+        pad = 1e-3f * fabsf(p[3]);
+        break;
+    case PT_SHAPE_MOVING_SPHERE:
+        for (int k = 0; k < 3; k++) {
+            const float f = (times[k] - p[6]) / (p[7] - p[6]);
+            const float cx = p[0] + f * (p[3] - p[0]), cy = p[1] + f * (p[4] - p[1]), cz = p[2] + f * (p[5] - p[2]);
+            grow(b, cx - p[8], cy - p[8], cz - p[8]);
+            grow(b, cx + p[8], cy + p[8], cz + p[8]);
+        }
+        pad = 1e-3f * fabsf(p[8]);
+        break;
+    case PT_SHAPE_RECT_XY: grow(b, p[0], p[2], p[4] - 1e-4f); grow(b, p[1], p[3], p[4] + 1e-4f); break;
+    case PT_SHAPE_RECT_XZ: grow(b, p[0], p[4] - 1e-4f, p[2]); grow(b, p[1], p[4] + 1e-4f, p[3]); break;
+    case PT_SHAPE_RECT_YZ: grow(b, p[4] - 1e-4f, p[0], p[2]); grow(b, p[4] + 1e-4f, p[1], p[3]); break;
+    case PT_SHAPE_BOX: grow(b, p[0], p[1], p[2]); grow(b, p[3], p[4], p[5]); break;
+    case PT_SHAPE_TRIANGLE:
+        grow(b, p[0], p[1], p[2]); grow(b, p[3], p[4], p[5]); grow(b, p[6], p[7], p[8]);
+        pad = 1e-4f;
+        break;
+    default: grow(b, 0, 0, 0);
+    }
+    // wrappers are stored outermost first; undo them innermost first on the 8 corners
+    for (int k = s.xform_count - 1; k >= 0; k--) {
+        const PtXform x = xforms[s.xform_first + k];
+        Box nb;
+        for (int a = 0; a < 3; a++) { nb.mn[a] = FLT_MAX; nb.mx[a] = -FLT_MAX; }
+        for (int c = 0; c < 8; c++) {
+            float cx = (c & 1) ? b.mx[0] : b.mn[0], cy = (c & 2) ? b.mx[1] : b.mn[1], cz = (c & 4) ? b.mx[2] : b.mn[2];
+            if (x.type == PT_XFORM_TRANSLATE) { cx += x.v[0]; cy += x.v[1]; cz += x.v[2]; }
+            else { const float nx = x.v[1] * cx + x.v[0] * cz, nz = -x.v[0] * cx + x.v[1] * cz; cx = nx; cz = nz; }
+            grow(nb, cx, cy, cz);
+        }
+        b = nb;
+    }
+    // absolute + relative slack so rounding in the leaf tests can never leave the box
+    for (int a = 0; a < 3; a++) {
+        const float m = fmaxf(fabsf(b.mn[a]), fabsf(b.mx[a]));
+        const float e = pad + 1e-5f * m + 1e-6f;
+        b.mn[a] -= e; b.mx[a] += e;
+    }
+    return b;
+}
+
+// float <-> order-preserving unsigned, for atomicMin / atomicMax on floats
+__device__ __forceinline__ unsigned f2o(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float o2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ void k_leaf_boxes(const PtShape* shapes, const PtXform* xforms, const PtObject* world, int n,
+                             float t0, float t1, Box* boxes, unsigned* cbounds)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float times[3] = { t0, t1, 0.0f };
+    const Box b = leaf_box(shapes, xforms, world[i].index, times);
+    boxes[i] = b;
+    for (int a = 0; a < 3; a++) {
+        const float c = 0.5f * (b.mn[a] + b.mx[a]);
+        atomicMin(&cbounds[a], f2o(c));
+        atomicMax(&cbounds[3 + a], f2o(c));
+    }
+}
+
+__device__ __forceinline__ unsigned spread3(unsigned v)     // 10 bits -> every third bit
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// key = morton30 << 32 | leaf number: unique, so the radix tree needs no tie handling
+__global__ void k_morton(const Box* boxes, int n, const unsigned* cbounds, uint64_t* keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = o2f(cbounds[a]), hi = o2f(cbounds[3 + a]);
+        const float c = 0.5f * (boxes[i].mn[a] + boxes[i].mx[a]);
+        const float ext = hi - lo;
+        float f = ext > 0.0f ? (c - lo) / ext : 0.0f;
+        f = fminf(fmaxf(f * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (unsigned)f;
+    }
+    const unsigned m = (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);
+    keys[i] = ((uint64_t)m << 32) | (unsigned)i;
+}
+
+// ---- stable LSD radix sort, 8 bits per pass, one wave per 1024-key tile ------------------------
+constexpr int TILE = 1024;
+
+__global__ __launch_bounds__(64) void k_radix_hist(const uint64_t* keys, int n, int shift, unsigned* hist, int n_tiles)
+{
+    __shared__ unsigned h[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) h[d] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * TILE;
+    for (int j = lane; j < TILE; j += 64) {
+        const int i = base + j;
+        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int d = lane; d < 256; d += 64) hist[(size_t)d * n_tiles + blockIdx.x] = h[d];
+}
+
+// exclusive scan of hist (digit-major, tile-minor) by one workgroup
+__global__ __launch_bounds__(1024) void k_radix_scan(unsigned* hist, int total)
+{
+    __shared__ unsigned part[1024];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned v = (i < total) ? hist[i] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            unsigned add = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const unsigned incl = part[threadIdx.x];
+        if (i < total) hist[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+}
+
+// Each 64-key chunk is ranked with ballots: lanes holding the same digit find each other by
+// AND-ing the eight per-bit ballots, their rank is the popcount of lower peers.
+__global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t* in, uint64_t* out, int n, int shift,
+                                                      const unsigned* hist, int n_tiles)
+{
+    __shared__ unsigned offs[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) offs[d] = hist[(size_t)d * n_tiles + blockIdx.x];
+    __syncthreads();
+    const int base = blockIdx.x * TILE;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int j = 0; j < TILE; j += 64) {
+        const int i = base + j + lane;
+        const bool live = i < n;
+        const uint64_t key = live ? in[i] : 0;
+        const unsigned digit = (unsigned)(key >> shift) & 255u;
+        unsigned long long peers = __ballot(live);
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot(live && ((digit >> b) & 1u));
+            peers &= ((digit >> b) & 1u) ? m : ~m;
+        }
+        const unsigned rank = (unsigned)__popcll(peers & lt);
+        const unsigned count = (unsigned)__popcll(peers);
+        unsigned dst = 0;
+        if (live) dst = offs[digit] + rank;
+        __syncthreads();
+        if (live && rank == count - 1) offs[digit] += count;
+        __syncthreads();
+        if (live) out[dst] = key;
+    }
+}
+
+// ---- Karras radix tree ------------------------------------------------------------------------------
+__device__ __forceinline__ int delta(const uint64_t* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __clzll(keys[i] ^ keys[j]);
+}
+
+// internal node i of n-1; leaves are referred to as ~leaf_number in left/right
+__global__ void k_karras(const uint64_t* keys, int n, int* left, int* right, int* parent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const int lc = (lo == gamma) ? ~gamma : gamma;
+    const int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    left[i] = lc; right[i] = rc;
+    if (lc >= 0) parent[lc] = i;
+    if (rc >= 0) parent[rc] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+// One sweep of bottom-up fitting: an internal node whose children are both fitted gets its box.
+// Sweeps are separate launches, so no in-kernel hand-off between workgroups is needed.
+__global__ void k_fit_sweep(const int* left, const int* right, const uint64_t* keys, const Box* leaf_boxes,
+                            Box* node_boxes, int* ready, int n_internal, int* n_changed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal || ready[i]) return;
+    const int lc = left[i], rc = right[i];
+    if ((lc >= 0 && ready[lc] != 1) || (rc >= 0 && ready[rc] != 1)) return;   // 1 = fitted by an earlier sweep
+    const Box a = (lc >= 0) ? node_boxes[lc] : leaf_boxes[(unsigned)keys[~lc]];
+    const Box b = (rc >= 0) ? node_boxes[rc] : leaf_boxes[(unsigned)keys[~rc]];
+    Box u;
+    for (int k = 0; k < 3; k++) { u.mn[k] = fminf(a.mn[k], b.mn[k]); u.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+    node_boxes[i] = u;
+    ready[i] = 2;            // fitted in this sweep; k_fit_commit turns it into 1 for the next one
+    atomicAdd(n_changed, 1);
+}
+__global__ void k_fit_commit(int* ready, int n_internal)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_internal && ready[i] == 2) ready[i] = 1;
+}
+
+// final 64-byte nodes: child boxes inline, leaf links rewritten to ~shape_index
+__global__ void k_emit(const int* left, const int* right, const uint64_t* keys, const Box* leaf_boxes, const Box* node_boxes,
+                       const PtObject* world, int n_internal, LbvhNode* nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    const int lc = left[i], rc = right[i];
+    const Box a = (lc >= 0) ? node_boxes[lc] : leaf_boxes[(unsigned)keys[~lc]];
+    const Box b = (rc >= 0) ? node_boxes[rc] : leaf_boxes[(unsigned)keys[~rc]];
+    LbvhNode nd;
+    for (int k = 0; k < 3; k++) { nd.lmin[k] = a.mn[k]; nd.lmax[k] = a.mx[k]; nd.rmin[k] = b.mn[k]; nd.rmax[k] = b.mx[k]; }
+    nd.left = (lc >= 0) ? lc : ~world[(unsigned)keys[~lc]].index;
+    nd.right = (rc >= 0) ? rc : ~world[(unsigned)keys[~rc]].index;
+    nd.pad0 = 0; nd.pad1 = 0;
+    nodes[i] = nd;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess; }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+int hip_fail(hipError_t e, const char* what)
+{
+    std::string msg = std::string("lbvh_build: ") + what + ": " + hipGetErrorName(e);
+    pt::set_error(msg.c_str());
+    return PT_ERR_HIP;
+}
+
+}  // namespace
+
+namespace pt {
+
+int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,
+               void** d_nodes_out, int* n_nodes_out, int* root_out)
+{
+    const int n = desc->n_world;
+    *d_nodes_out = nullptr; *n_nodes_out = 0; *root_out = 0;
+    for (int i = 0; i < n; i++) {
+        if (desc->world[i].type != PT_OBJ_SHAPE) { set_error("lbvh_build: world list holds a non-shape entry"); return PT_ERR_UNSUPPORTED; }
+        if (i > 0 && desc->world[i].index <= desc->world[i - 1].index) {
+            set_error("lbvh_build: world shape indices must be strictly increasing (list order decides ties)");
+            return PT_ERR_UNSUPPORTED;
+        }
+    }
+    if (n < 2) { set_error("lbvh_build: fewer than two shapes"); return PT_ERR_INVALID; }
+
+    const int n_int = n - 1;
+    const int n_tiles = (n + TILE - 1) / TILE;
+    DevBuf world, boxes, cb, keys_a, keys_b, hist, left, right, parent, nboxes, ready, changed;
+    if (!world.alloc((size_t)n * sizeof(PtObject)) || !boxes.alloc((size_t)n * sizeof(Box)) || !cb.alloc(6 * sizeof(unsigned)) ||
+        !keys_a.alloc((size_t)n * 8) || !keys_b.alloc((size_t)n * 8) || !hist.alloc((size_t)256 * n_tiles * 4) ||
+        !left.alloc((size_t)n_int * 4) || !right.alloc((size_t)n_int * 4) || !parent.alloc((size_t)n_int * 4) ||
+        !nboxes.alloc((size_t)n_int * sizeof(Box)) || !ready.alloc((size_t)n_int * 4) || !changed.alloc(4)) {
+        set_error("lbvh_build: out of device memory");
+        return PT_ERR_OOM;
+    }
+    hipError_t e;
+    if ((e = hipMemcpy(world.p, desc->world, (size_t)n * sizeof(PtObject), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "copy world");
+    const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    if ((e = hipMemcpy(cb.p, init, sizeof init, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "init bounds");
+
+    const int B = 256, G = (n + B - 1) / B, GI = (n_int + B - 1) / B;
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, nullptr, d_shapes, d_xforms, world.as<PtObject>(), n,
+                       desc->camera[21], desc->camera[22], boxes.as<Box>(), cb.as<unsigned>());
+    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, nullptr, boxes.as<Box>(), n, cb.as<unsigned>(), keys_a.as<uint64_t>());
+    // the low 32 key bits (leaf number) are already ascending: four stable passes over the Morton bits
+    uint64_t* src = keys_a.as<uint64_t>();
+    uint64_t* dst = keys_b.as<uint64_t>();
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 32 + 8 * pass;
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(64), 0, nullptr, src, n, shift, hist.as<unsigned>(), n_tiles);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, hist.as<unsigned>(), 256 * n_tiles);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(64), 0, nullptr, src, dst, n, shift, hist.as<unsigned>(), n_tiles);
+        uint64_t* tmp = src; src = dst; dst = tmp;
+    }
+    hipLaunchKernelGGL(k_karras, dim3(GI), dim3(B), 0, nullptr, src, n, left.as<int>(), right.as<int>(), parent.as<int>());
+    if ((e = hipMemset(ready.p, 0, (size_t)n_int * 4)) != hipSuccess) return hip_fail(e, "memset ready");
+    bool fitted = false;
+    for (int sweep = 0; sweep < 80 && !fitted; sweep++) {
+        if ((e = hipMemset(changed.p, 0, 4)) != hipSuccess) return hip_fail(e, "memset changed");
+        hipLaunchKernelGGL(k_fit_sweep, dim3(GI), dim3(B), 0, nullptr, left.as<int>(), right.as<int>(), src, boxes.as<Box>(),
+                           nboxes.as<Box>(), ready.as<int>(), n_int, changed.as<int>());
+        hipLaunchKernelGGL(k_fit_commit, dim3(GI), dim3(B), 0, nullptr, ready.as<int>(), n_int);
+        int h_changed = 0;
+        if ((e = hipMemcpy(&h_changed, changed.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "read sweep count");
+        if (h_changed == 0) fitted = true;
+    }
+    int root_ready = 0;
+    if ((e = hipMemcpy(&root_ready, ready.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "read root flag");
+    if (!root_ready) { set_error("lbvh_build: tree deeper than the fitting sweeps allow"); return PT_ERR_UNSUPPORTED; }
+
+    void* nodes = nullptr;
+    if ((e = hipMalloc(&nodes, (size_t)n_int * sizeof(LbvhNode))) != hipSuccess) { set_error("lbvh_build: out of device memory"); return PT_ERR_OOM; }
+    hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, nullptr, left.as<int>(), right.as<int>(), src, boxes.as<Box>(), nboxes.as<Box>(),
+                       world.as<PtObject>(), n_int, static_cast<LbvhNode*>(nodes));
+    if ((e = hipDeviceSynchronize()) != hipSuccess) { (void)hipFree(nodes); return hip_fail(e, "kernels"); }
+    *d_nodes_out = nodes;
+    *n_nodes_out = n_int;
+    *root_out = 0;             // Karras' root is internal node 0
+    return PT_OK;
+}
+
+}  // namespace pt

@@ -1,0 +1,252 @@
+/*
+ * ptcore.h - C ABI of the MI355X path-tracing core.
+ *
+ * The reference (rweyrauch/gpupathtracer) has no plugin interface: its one
+ * host<->device seam is the `if (!cpu) { ... }` block of main()
+ * (src/ptMain.cu:579-653), which serialises a pointer-linked scene, has a
+ * <<<1,1>>> kernel rebuild it with device-side `new`
+ * (allocate_world_kernel, src/ptMain.cu:423-430), launches render_kernel
+ * (src/ptMain.cu:171-190) and copies nx*ny float3 back.  This header is the
+ * C ABI a maintainer binds in place of that block.  The scene crosses the
+ * boundary as flat arrays with type tags instead of a byte stream of virtual
+ * objects; results (closest hit, image) are defined to be those of the
+ * reference's host-compiled hit/material/integrator code.
+ *
+ * All structs are plain old data, 4-byte fields only, no padding surprises.
+ * All pointers in PtSceneDesc are host pointers; the library copies what it
+ * needs at pt_scene_create() time and the caller may free them afterwards.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- type tags ---------------------------------------------------------- */
+
+/* Leaf geometry; replaces the Hitable subclasses of include/ptHitable.h:32-49. */
+enum PtShapeType {
+    PT_SHAPE_SPHERE        = 1, /* p = cx cy cz r                       (include/ptSphere.h:30-79)    */
+    PT_SHAPE_MOVING_SPHERE = 2, /* p = c0xyz c1xyz t0 t1 r              (include/ptSphere.h:81-122)   */
+    PT_SHAPE_RECT_XY       = 3, /* p = x0 x1 y0 y1 k                    (include/ptRectangle.h:24-54) */
+    PT_SHAPE_RECT_XZ       = 4, /* p = x0 x1 z0 z1 k                    (include/ptRectangle.h:56-106)*/
+    PT_SHAPE_RECT_YZ       = 5, /* p = y0 y1 z0 z1 k                    (include/ptRectangle.h:108-138)*/
+    PT_SHAPE_BOX           = 6, /* p = pmin xyz, pmax xyz; six rects    (include/ptRectangle.h:194-260)*/
+    PT_SHAPE_TRIANGLE      = 7  /* p = v0 xyz, v1 xyz, v2 xyz           (include/ptTriangle.h:19-54)  */
+};
+
+/* PtShape.flags */
+enum { PT_FLIP_NORMAL = 1 };  /* odd number of FlipNormals wrappers (include/ptRectangle.h:140-192) */
+
+/* Instance wrappers, applied outermost first (include/ptRectangle.h:262-445). */
+enum PtXformType {
+    PT_XFORM_TRANSLATE = 1,   /* v = offset xyz            */
+    PT_XFORM_ROTATE_Y  = 2    /* v = sinTheta cosTheta 0   */
+};
+
+/* include/ptMaterial.h:39-46 */
+enum PtMaterialType {
+    PT_MAT_LAMBERTIAN    = 1, /* texture = albedo                       */
+    PT_MAT_METAL         = 2, /* albedo rgb, param = fuzz (already <=1) */
+    PT_MAT_DIELECTRIC    = 3, /* param = refractive index               */
+    PT_MAT_DIFFUSE_LIGHT = 4, /* texture = emission                     */
+    PT_MAT_ISOTROPIC     = 5  /* texture = albedo                       */
+};
+
+/* include/ptTexture.h:19-25 */
+enum PtTextureType {
+    PT_TEX_CONSTANT = 1,      /* color                                   */
+    PT_TEX_CHECKER  = 2,      /* scale (reference: 10), odd, even        */
+    PT_TEX_NOISE    = 3,      /* scale                                   */
+    PT_TEX_IMAGE    = 4       /* nx, ny, texel_offset into texels (RGB8) */
+};
+
+/* Entries of the ordered top-level world list (HitableList, src/ptHitableList.cu:12-27). */
+enum PtObjectType {
+    PT_OBJ_SHAPE  = 1,        /* index into shapes  */
+    PT_OBJ_MEDIUM = 2,        /* index into media   */
+    PT_OBJ_BVH    = 3         /* index into bvhs    */
+};
+
+/* include/ptAmbientLight.h:18-22; NONE = null pointer (src/ptMain.cu:145-147). */
+enum PtAmbientType { PT_AMBIENT_NONE = 0, PT_AMBIENT_CONSTANT = 1, PT_AMBIENT_SKY = 2 };
+
+/* How the library may search the world list. */
+enum PtAccel {
+    PT_ACCEL_LIST = 0,        /* walk the list in order, exactly as HitableList::hit does           */
+    PT_ACCEL_LBVH = 1         /* library-built Morton LBVH over the list; same closest hit and the  */
+                              /* same winner on exact ties as the in-order walk (needs a list made  */
+                              /* only of PT_OBJ_SHAPE entries; otherwise falls back to LIST)        */
+};
+
+/* Which scheduler runs the radiance pipeline stages. */
+enum PtPipeline {
+    PT_PIPELINE_DEFAULT   = 0,
+    PT_PIPELINE_FUSED     = 1, /* one lane per pixel, stages fused, path regeneration in-lane   */
+    PT_PIPELINE_WAVEFRONT = 2  /* staged: generate / extend / shade (material-sorted) / light   */
+};
+
+/* Ids reported by pt_trace_closest. */
+#define PT_ID_MISS        (-1)
+#define PT_ID_MEDIUM_BASE 0x40000000   /* + index into media */
+
+/* ---- scene description -------------------------------------------------- */
+
+typedef struct PtShape {
+    int32_t type;         /* PtShapeType                                     */
+    int32_t flags;        /* PT_FLIP_NORMAL                                  */
+    int32_t material;     /* index into materials, -1 = none (light shapes)  */
+    int32_t xform_first;  /* first wrapper in xforms                         */
+    int32_t xform_count;  /* number of wrappers, outermost first             */
+    int32_t tri_uv;       /* TRIANGLE: index into tri_uvs, -1 = all zero     */
+    float   p[10];
+} PtShape;                /* 64 bytes */
+
+typedef struct PtTriUV { float uv0[2], uv1[2], uv2[2]; } PtTriUV;
+
+typedef struct PtXform { int32_t type; float v[3]; } PtXform;
+
+typedef struct PtMaterial {
+    int32_t type;
+    int32_t texture;      /* -1 = none */
+    float   albedo[3];
+    float   param;
+} PtMaterial;
+
+typedef struct PtTexture {
+    int32_t type;
+    int32_t odd, even;    /* CHECKER children (indices into textures) */
+    int32_t nx, ny;       /* IMAGE */
+    int32_t texel_offset; /* IMAGE: byte offset into texels */
+    float   color[3];
+    float   scale;
+} PtTexture;
+
+typedef struct PtObject { int32_t type; int32_t index; } PtObject;
+
+/* ConstantMedium (include/ptMedium.h:19-98): boundary shape, density, Isotropic material. */
+typedef struct PtMedium { int32_t boundary; float density; int32_t material; int32_t reserved; } PtMedium;
+
+/* Explicit binary tree, hit exactly as BVH::hit (src/ptBVH.cu:45-74): both children
+ * are always visited with the caller's [tmin,tmax]; the right child wins ties.
+ * child >= 0: node index; child < 0: ~child is a shape index. */
+typedef struct PtBvhNode { float bmin[3]; float bmax[3]; int32_t left; int32_t right; } PtBvhNode;
+typedef struct PtBvh { int32_t root; int32_t xform_first; int32_t xform_count; int32_t reserved; } PtBvh;
+
+typedef struct PtSceneDesc {
+    int32_t n_shapes;     const PtShape*    shapes;
+    int32_t n_tri_uvs;    const PtTriUV*    tri_uvs;
+    int32_t n_xforms;     const PtXform*    xforms;
+    int32_t n_materials;  const PtMaterial* materials;
+    int32_t n_textures;   const PtTexture*  textures;
+    int32_t n_texels;     const uint8_t*    texels;      /* RGB8 blobs of all IMAGE textures */
+    int32_t n_media;      const PtMedium*   media;
+    int32_t n_bvh_nodes;  const PtBvhNode*  bvh_nodes;
+    int32_t n_bvhs;       const PtBvh*      bvhs;
+    int32_t n_world;      const PtObject*   world;       /* ordered top-level list */
+    /* lightShapes argument of color() (src/ptMain.cu:95,119-127): shape indices.
+     * lights_is_list != 0 reproduces a HitableList of lights (uniform mixture,
+     * one extra RNG draw per sample, include/ptHitableList.h:29-44). */
+    int32_t n_lights;     const int32_t*    lights;
+    int32_t lights_is_list;
+    int32_t ambient_type; /* PtAmbientType */
+    float   ambient_color[3];
+    /* Camera members in declaration order (include/ptCamera.h:43-49):
+     * origin, lowerLeftCorner, horizontal, vertical, u, v, w, time0, time1, lens_radius */
+    float   camera[24];
+    int32_t accel;        /* PtAccel */
+} PtSceneDesc;
+
+typedef struct PtRenderParams {
+    int32_t nx, ny;       /* image size; out_rgb holds nx*ny*3 floats, row 0 = top (src/ptMain.cu:178) */
+    int32_t ns;           /* samples per pixel                                                        */
+    int32_t max_depth;    /* bounce limit (reference default 25, src/ptMain.cu:524)                   */
+    /* Sharding: the image is cut into tile_w x tile_h tiles numbered row-major from the
+     * top-left; this call renders the tiles with (tile % shard_count) == shard_index and
+     * writes 0 to every other pixel, so shards sum to the whole frame.  0,0 -> 8x8 tiles. */
+    int32_t shard_index, shard_count;
+    int32_t tile_w, tile_h;
+    int32_t pipeline;     /* PtPipeline */
+    int32_t reserved[7];
+} PtRenderParams;
+
+/* One ray for pt_trace_closest.  The hit range is the integrator's [0.001, FLT_MAX]
+ * (src/ptMain.cu:104).  seed feeds the per-ray PCG stream that ConstantMedium::hit
+ * draws from (include/ptMedium.h:43); it is unused in scenes without media. */
+typedef struct PtRay { float o[3]; float d[3]; float time; uint32_t seed; } PtRay;   /* 32 bytes */
+
+/* Timings of the most recent pt_render*/
+typedef struct PtRenderStats {
+    float    kernel_ms;      /* HIP-event time of the radiance kernel(s) on their stream */
+    float    total_ms;       /* HIP-event time of the whole call on that stream          */
+    int32_t  n_launches;     /* kernel launches in the call                               */
+    int32_t  pipeline;       /* scheduler that ran                                        */
+    uint64_t paths;          /* camera samples traced by this call (this shard only)      */
+    uint64_t reserved[4];
+} PtRenderStats;
+
+typedef struct PtScene PtScene;
+
+/* ---- entry points -------------------------------------------------------- */
+
+/* Every function returns 0 on success or a negative PtError; the text of the last
+ * failure on the calling thread is available from pt_last_error().  The reference
+ * prints to std::cerr and returns EXIT_FAILURE instead (src/ptMain.cu:606-610,642-646). */
+enum PtError {
+    PT_OK = 0, PT_ERR_INVALID = -1, PT_ERR_NO_DEVICE = -2, PT_ERR_HIP = -3,
+    PT_ERR_UNSUPPORTED = -4, PT_ERR_OOM = -5
+};
+const char* pt_last_error(void);
+
+/* Replaces scene serialisation + allocate_world_kernel (src/ptMain.cu:560-572,603,423-430):
+ * validates the description, uploads it to the current HIP device and, for
+ * PT_ACCEL_LBVH, builds the Morton/radix LBVH on the device (in place of
+ * BVH::BVH + quickSort, src/ptBVH.cu:15-43, src/ptQuickSort.cu:40-81). */
+int  pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene);
+void pt_scene_destroy(PtScene* scene);
+
+/* Replaces render_kernel launch + cudaMemcpy (src/ptMain.cu:612-649).  out_rgb is a host
+ * buffer of nx*ny*3 floats: averaged, sqrt-gamma'd colour exactly as render_pixel returns
+ * it (src/ptMain.cu:153-169), pixel index (ny-y-1)*nx+x.  Blocking. */
+int  pt_render(PtScene* scene, const PtRenderParams* params, float* out_rgb);
+
+/* Same, but d_out_rgb is device memory on the scene's device and the work is queued on
+ * hip_stream (a hipStream_t, NULL = default stream) without a host sync. */
+int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_rgb, void* hip_stream);
+
+/* Closest hit of world->hit(ray, 0.001f, FLT_MAX) (src/ptMain.cu:104) for n rays:
+ * prim_id = winning shape index (or PT_ID_MEDIUM_BASE+m, or PT_ID_MISS), t = rec.t.
+ * Host pointers; blocking. */
+int  pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, int32_t* prim_id, float* t);
+
+/* Fills *stats with the timings of the scene's most recent render call; waits for it. */
+int  pt_render_stats(PtScene* scene, PtRenderStats* stats);
+
+/* Copies the library-built LBVH (64-byte nodes, see DESIGN) to the host for inspection:
+ * returns the node count, or a negative error; nodes may be NULL to query the count. */
+int  pt_scene_lbvh_nodes(PtScene* scene, void* nodes, size_t capacity_bytes);
+
+/* The reference's hard-coded scene builders (src/ptMain.cu:192-421) restated as
+ * description factories.  name is one of "simple_spheres", "simple_light", "random",
+ * "cornell", "cornell_spheres", "final", "trimesh".  The returned description and all its
+ * arrays are owned by the library until pt_scene_desc_free().  earth_rgb/earth_nx/earth_ny
+ * optionally supply the decoded earthmap.jpg texels for "final" (may be NULL/0: the earth
+ * sphere is then left out, as in the reference's device branch, src/ptMain.cu:396-402). */
+int  pt_scene_desc_builtin(const char* name, float aspect,
+                           const uint8_t* earth_rgb, int32_t earth_nx, int32_t earth_ny,
+                           PtSceneDesc** out_desc);
+/* "trimesh" with an explicit grid resolution: (n+1)^2 vertices, 2*n*n triangles. */
+int  pt_scene_desc_trimesh(int32_t grid_n, float aspect, PtSceneDesc** out_desc);
+void pt_scene_desc_free(PtSceneDesc* desc);
+
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int  pt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */
