@@ -9,7 +9,9 @@
 // Arithmetic contract: every float expression is evaluated in the reference's order with
 // one rounding per operation (build with -ffp-contract=off; HIP's default correctly-rounded
 // fp32 divide and sqrt).  Where the reference's C++ leaves an order unspecified the order
-// g++ picks is used (z before x in XZRectangle::random).
+// g++ picks is used (z before x in XZRectangle::random).  sin, cos, log and pow(.,5) are the
+// host libm's results bit for bit (pt_libm.h); atan2f/asinf (MovingSphere uv, read only by image
+// textures) are the device library's.
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H
 
@@ -18,6 +20,7 @@
 #include <cstdint>
 
 #include "../../include/ptcore.h"
+#include "pt_libm.h"
 
 namespace ptd {
 
@@ -127,13 +130,13 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Pcg& g)
     const float phi = g.rand() * 2 * PI_F;
     const float z = 1 - 2 * g.rand();
     const float r = sqrtf(fmaxf(0.0f, 1 - z * z));
-    return mk(r * cosf(phi), r * sinf(phi), z);
+    return mk(r * ptm::cosf_glibc(phi), r * ptm::sinf_glibc(phi), z);
 }
 __device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
 {
     const float r = sqrtf(g.rand());
     const float theta = g.rand() * 2 * PI_F;
-    return mk(r * cosf(theta), r * sinf(theta), 0.0f);
+    return mk(r * ptm::cosf_glibc(theta), r * ptm::sinf_glibc(theta), 0.0f);
 }
 __device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
 {
@@ -141,8 +144,8 @@ __device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
     float r2 = g.rand();
     float z = sqrtf(1 - r2);
     float phi = 2 * PI_F * r1;
-    float x = cosf(phi) * 2 * sqrtf(r2);
-    float y = sinf(phi) * 2 * sqrtf(r2);
+    float x = ptm::cosf_glibc(phi) * 2 * sqrtf(r2);
+    float y = ptm::sinf_glibc(phi) * 2 * sqrtf(r2);
     return mk(x, y, z);
 }
 __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqrd, Pcg& g)
@@ -151,8 +154,8 @@ __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqr
     float r2 = g.rand();
     float z = 1 + r2 * (sqrtf(1 - radius * radius / dist_sqrd) - 1);
     float phi = 2 * PI_F * r1;
-    float x = cosf(phi) * sqrtf(1 - z * z);
-    float y = sinf(phi) * sqrtf(1 - z * z);
+    float x = ptm::cosf_glibc(phi) * sqrtf(1 - z * z);
+    float y = ptm::sinf_glibc(phi) * sqrtf(1 - z * z);
     return mk(x, y, z);
 }
 
@@ -430,7 +433,7 @@ __device__ __forceinline__ bool medium_t(const SceneView& sv, int m, const Ray& 
             if (ta > tb) return false;
             if (ta < 0) ta = 0;
             float dist_inside = (tb - ta) * len(r.d);
-            float hit_dist = -(1 / med.density) * logf(g.rand());
+            float hit_dist = -(1 / med.density) * ptm::logf_glibc(g.rand());
             if (hit_dist < dist_inside) {
                 t = ta + hit_dist / len(r.d);
                 return true;
@@ -733,12 +736,12 @@ __device__ __forceinline__ V3 texture_value(const SceneView& sv, int tex, float 
     if (F & F_CHECKER) {
         // nested checkers resolve iteratively (:90-97)
         for (int guard = 0; guard < 8 && t.type == PT_TEX_CHECKER; guard++) {
-            float sines = sinf(t.scale * p.x) * sinf(t.scale * p.y) * sinf(t.scale * p.z);
+            float sines = ptm::sinf_glibc(t.scale * p.x) * ptm::sinf_glibc(t.scale * p.y) * ptm::sinf_glibc(t.scale * p.z);
             t = sv.textures[(sines < 0) ? t.odd : t.even];
         }
     }
     if ((F & F_NOISE) && t.type == PT_TEX_NOISE) {                  // :142-146
-        float n = 0.5f * (1 + sinf(t.scale * p.z + 10 * turbulence7(p)));
+        float n = 0.5f * (1 + ptm::sinf_glibc(t.scale * p.z + 10 * turbulence7(p)));
         return mk(n, n, n);
     }
     if ((F & F_IMAGE) && t.type == PT_TEX_IMAGE) {                  // :187-199
@@ -826,7 +829,7 @@ __device__ __forceinline__ float schlick(float cs, float ri)                    
 {
     float r0 = (1 - ri) / (1 + ri);
     r0 = r0 * r0;
-    return r0 + (1 - r0) * powf(1 - cs, 5.0f);
+    return r0 + (1 - r0) * ptm::pow5f_glibc(1 - cs);
 }
 
 // ---- one bounce of color() (src/ptMain.cu:101-148) --------------------------------------------------------
