@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s, whole job, Cornell box 1024x1024 at 4096 spp (BASELINE.json
+configs[2]), tile-sharded over N MI355X of one node.
+
+One process per GPU (the driver starts N of them through torch.distributed.run).  A "step" is one
+complete render of the frame: every rank traces its 8x8-tile shard of the image with the scene
+already resident in HBM, then the shards are summed onto rank 0 with one RCCL reduce over xGMI.
+A path is one camera sample (one color() call of the reference, src/ptMain.cu:161).
+
+torch.distributed is used for rendezvous, barriers and the max-over-ranks clock only (gloo, CPU):
+the wheel's bundled HIP runtime and the system ROCm runtime this library links cannot both drive
+the GPU in one process, so device memory, streams and the RCCL communicator live in the library.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# Algorithmic work of one Cornell path under the reference's arithmetic (one FLOP = one fp32
+# add/sub/mul/compare/min/max/div/sqrt, no FMA credit because parity forbids contraction):
+# 52.4 rectangle tests, 2.81 closest-hit searches and 1.81 diffuse scatters per path.
+FLOP_PER_PATH = {"cornell": 1200.0}
+# fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).
+PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=4096)
+    ap.add_argument("--depth", type=int, default=25)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import gpupathtracer_amd as pt
+
+    n_dev = pt.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no HIP device visible")
+    pt.set_device(local_rank % n_dev)
+
+    nx = ny = args.size
+    desc = pt.builtin_scene(args.scene, float(nx) / float(ny))
+    scene = pt.Scene(desc)
+    n_floats = 3 * nx * ny
+    frame = pt.DeviceBuffer(n_floats * 4)
+
+    collective = "none"
+    comm = None
+    if world > 1:
+        import torch
+        uid = [pt.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            if os.environ.get("PT_BENCH_COLLECTIVE", "rccl") != "rccl":      # rehearsal on a one-GPU box
+                raise pt.PtError(0, "RCCL disabled by PT_BENCH_COLLECTIVE")
+            comm = pt.Comm(uid[0], rank, world)
+            collective = "rccl-reduce"
+        except pt.PtError as e:      # keep the run alive, but say so in the result line
+            sys.stderr.write("[bench] RCCL communicator failed (%s); gathering frames through host/gloo\n" % e)
+            collective = "gloo-host-reduce"
+        flag = torch.tensor([1 if comm is not None else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            collective = "gloo-host-reduce"
+
+    kernel_ms = []
+
+    def step(record):
+        scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, shard_index=rank, shard_count=world, tile=(8, 8))
+        if record:
+            kernel_ms.append(scene.stats().kernel_ms)      # HIP events on the launch stream
+        if world > 1:
+            if comm is not None:
+                comm.reduce_frame(frame.ptr, n_floats, root=0)
+            else:
+                import torch
+                host = torch.from_numpy(frame.to_host())
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    pt.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    pt.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    paths_per_step = nx * ny * args.spp
+    value = paths_per_step * args.steps / dt / 1e6
+    result = None
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        shard_paths = scene.stats().paths            # paths this rank's launch traced
+        flop = FLOP_PER_PATH.get(args.scene)
+        roofline = None
+        if flop is not None:
+            achieved = shard_paths * flop / (k_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None,
+                        "kernel": "k_render_fused", "kernel_ms": k_ms, "flop_per_path": flop,
+                        "paths_per_launch": shard_paths}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from tests import _oracle
+            orc = _oracle.load()
+            threads = max(1, min(16, os.cpu_count() or 1))
+            c0 = time.perf_counter()
+            orc.render(desc, nx, ny, args.cpu_spp, args.depth, threads=threads)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": nx * ny * args.cpu_spp / cdt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+                   "sample": "%s %dx%d at %d spp, depth %d, OpenMP rows over %d threads" %
+                             (args.scene, nx, ny, args.cpu_spp, args.depth, threads)}
+        result = {
+            "metric": "Mpaths/s whole node, Cornell 1024^2 4096spp",
+            "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s_box %dx%d %dspp depth%d (BASELINE configs[2])" % (args.scene, nx, ny, args.spp, args.depth)
+                       if args.scene == "cornell" else "%s %dx%d %dspp depth%d" % (args.scene, nx, ny, args.spp, args.depth),
+                       "sharding": "8x8 pixel tiles round-robin over ranks", "pipeline": "fused", "collective": collective},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -6,10 +6,11 @@ that ABI for tests and benchmarks; it contains no rendering code of its own and 
 library has not been built -- there is no CPU fallback.
 """
 from .api import (  # noqa: F401
-    PtError, Scene, SceneDesc, RenderStats, builtin_scene, trimesh_scene, device_count,
-    library, library_path,
+    PtError, Scene, SceneDesc, RenderStats, DeviceBuffer, Comm, builtin_scene, trimesh_scene,
+    device_count, set_device, synchronize, libm_eval, library, library_path,
 )
 from . import _abi as abi  # noqa: F401
 
-__all__ = ["PtError", "Scene", "SceneDesc", "RenderStats", "builtin_scene", "trimesh_scene",
-           "device_count", "library", "library_path", "abi"]
+__all__ = ["PtError", "Scene", "SceneDesc", "RenderStats", "DeviceBuffer", "Comm", "builtin_scene",
+           "trimesh_scene", "device_count", "set_device", "synchronize", "libm_eval", "library",
+           "library_path", "abi"]

@@ -103,4 +103,6 @@ EXPORTS = [
     "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_trace_closest", "pt_render_stats", "pt_scene_lbvh_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_device_count",
+    "pt_set_device", "pt_device_synchronize", "pt_device_malloc", "pt_device_free", "pt_memcpy_to_host",
+    "pt_comm_unique_id", "pt_comm_init", "pt_comm_reduce_frame", "pt_comm_destroy", "pt_libm_eval",
 ]

@@ -54,6 +54,18 @@ def library():
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
     lib.pt_scene_desc_free.restype = None
     lib.pt_device_count.argtypes = []
+    lib.pt_set_device.argtypes = [C.c_int]
+    lib.pt_device_synchronize.argtypes = []
+    lib.pt_device_malloc.argtypes = [C.c_size_t, P(C.c_void_p)]
+    lib.pt_device_free.argtypes = [C.c_void_p]
+    lib.pt_device_free.restype = None
+    lib.pt_memcpy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.pt_comm_unique_id.argtypes = [C.c_void_p]
+    lib.pt_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
+    lib.pt_comm_reduce_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    lib.pt_comm_destroy.argtypes = [C.c_void_p]
+    lib.pt_comm_destroy.restype = None
+    lib.pt_libm_eval.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     _LIB = lib
     return lib
 
@@ -65,6 +77,74 @@ def _check(rc):
 
 def device_count():
     return int(library().pt_device_count())
+
+
+def set_device(index):
+    _check(library().pt_set_device(int(index)))
+
+
+def synchronize():
+    _check(library().pt_device_synchronize())
+
+
+class DeviceBuffer:
+    """Device memory owned by the library's HIP runtime."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(library().pt_device_malloc(nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def to_host(self, dtype=np.float32):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype)
+        _check(library().pt_memcpy_to_host(out.ctypes.data, C.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def close(self):
+        if self.ptr:
+            library().pt_device_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator of one rank (one process per GPU)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(library().pt_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def __init__(self, unique_id, rank, world):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(library().pt_comm_init(buf, rank, world, C.byref(h)))
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def reduce_frame(self, dev_ptr, n_floats, root=0, stream=None):
+        _check(library().pt_comm_reduce_frame(self._h, C.c_void_p(dev_ptr), n_floats, root,
+                                              C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self._h is not None:
+            library().pt_comm_destroy(self._h)
+            self._h = None
+
+
+def libm_eval(fn, x, on_device):
+    """fn: 0 sin, 1 cos, 2 log, 3 x**5 -- the library's libm replacements on float32 inputs."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    _check(library().pt_libm_eval(int(fn), x.ctypes.data, x.size, out.ctypes.data, 1 if on_device else 0))
+    return out
 
 
 class SceneDesc:

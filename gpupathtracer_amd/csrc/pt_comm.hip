@@ -1,0 +1,150 @@
+// Device plumbing, the RCCL frame exchange and the libm diagnostics of the C ABI (include/ptcore.h).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+
+#include "pt_host.h"
+#include "pt_libm.h"
+
+namespace {
+
+int hip_err(hipError_t e, const char* what)
+{
+    std::string msg = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+    pt::set_error(msg.c_str());
+    return PT_ERR_HIP;
+}
+int nccl_err(ncclResult_t r, const char* what)
+{
+    std::string msg = std::string(what) + ": " + ncclGetErrorString(r);
+    pt::set_error(msg.c_str());
+    return PT_ERR_HIP;
+}
+
+__global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r;
+    switch (fn) {
+    case 0: r = ptm::sinf_glibc(v); break;
+    case 1: r = ptm::cosf_glibc(v); break;
+    case 2: r = ptm::logf_glibc(v); break;
+    default: r = ptm::pow5f_glibc(v); break;
+    }
+    out[i] = r;
+}
+
+}  // namespace
+
+struct PtComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" int pt_set_device(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    return e == hipSuccess ? PT_OK : hip_err(e, "hipSetDevice");
+}
+
+extern "C" int pt_device_synchronize(void)
+{
+    hipError_t e = hipDeviceSynchronize();
+    return e == hipSuccess ? PT_OK : hip_err(e, "hipDeviceSynchronize");
+}
+
+extern "C" int pt_device_malloc(size_t bytes, void** out)
+{
+    if (!out) { pt::set_error("pt_device_malloc: null argument"); return PT_ERR_INVALID; }
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+    if (e != hipSuccess) { hip_err(e, "hipMalloc"); return PT_ERR_OOM; }
+    return PT_OK;
+}
+
+extern "C" void pt_device_free(void* p)
+{
+    if (p) (void)hipFree(p);
+}
+
+extern "C" int pt_memcpy_to_host(void* dst, const void* src, size_t bytes)
+{
+    if (!dst || !src) { pt::set_error("pt_memcpy_to_host: null argument"); return PT_ERR_INVALID; }
+    hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? PT_OK : hip_err(e, "hipMemcpy");
+}
+
+extern "C" int pt_comm_unique_id(void* id128)
+{
+    if (!id128) { pt::set_error("pt_comm_unique_id: null argument"); return PT_ERR_INVALID; }
+    static_assert(sizeof(ncclUniqueId) == 128, "unique id is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return nccl_err(r, "ncclGetUniqueId");
+    std::memcpy(id128, &id, sizeof id);
+    return PT_OK;
+}
+
+extern "C" int pt_comm_init(const void* id128, int rank, int world, PtComm** out)
+{
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) { pt::set_error("pt_comm_init: bad arguments"); return PT_ERR_INVALID; }
+    *out = nullptr;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    PtComm* c = new PtComm();
+    c->rank = rank; c->world = world;
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { delete c; return nccl_err(r, "ncclCommInitRank"); }
+    *out = c;
+    return PT_OK;
+}
+
+extern "C" int pt_comm_reduce_frame(PtComm* c, void* d_frame, size_t n_floats, int root, void* hip_stream)
+{
+    if (!c || !d_frame || root < 0 || root >= c->world) { pt::set_error("pt_comm_reduce_frame: bad arguments"); return PT_ERR_INVALID; }
+    ncclResult_t r = ncclReduce(d_frame, d_frame, n_floats, ncclFloat, ncclSum, root, c->comm, static_cast<hipStream_t>(hip_stream));
+    if (r != ncclSuccess) return nccl_err(r, "ncclReduce");
+    return PT_OK;
+}
+
+extern "C" void pt_comm_destroy(PtComm* c)
+{
+    if (!c) return;
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device)
+{
+    if (fn < 0 || fn > 3 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
+    if (n == 0) return PT_OK;
+    if (!on_device) {
+        for (size_t i = 0; i < n; i++) {
+            switch (fn) {
+            case 0: out[i] = ptm::sinf_glibc(x[i]); break;
+            case 1: out[i] = ptm::cosf_glibc(x[i]); break;
+            case 2: out[i] = ptm::logf_glibc(x[i]); break;
+            default: out[i] = ptm::pow5f_glibc(x[i]); break;
+            }
+        }
+        return PT_OK;
+    }
+    float *dx = nullptr, *dy = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&dx, n * 4)) != hipSuccess) return hip_err(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&dy, n * 4)) != hipSuccess) { (void)hipFree(dx); return hip_err(e, "hipMalloc"); }
+    int rc = PT_OK;
+    if ((e = hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice)) != hipSuccess) rc = hip_err(e, "hipMemcpy");
+    if (rc == PT_OK) {
+        hipLaunchKernelGGL(k_libm_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, fn, dx, n, dy);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) rc = hip_err(e, "libm kernel");
+    }
+    if (rc == PT_OK && (e = hipMemcpy(out, dy, n * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = hip_err(e, "hipMemcpy");
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return rc;
+}

@@ -226,7 +226,7 @@ int  pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, int32_t* prim
 /* Fills *stats with the timings of the scene's most recent render call; waits for it. */
 int  pt_render_stats(PtScene* scene, PtRenderStats* stats);
 
-/* Copies the library-built LBVH (64-byte nodes, see DESIGN) to the host for inspection:
+/* Copies the library-built LBVH (64-byte nodes: two child boxes and two child links) to the host:
  * returns the node count, or a negative error; nodes may be NULL to query the count. */
 int  pt_scene_lbvh_nodes(PtScene* scene, void* nodes, size_t capacity_bytes);
 
@@ -245,6 +245,34 @@ void pt_scene_desc_free(PtSceneDesc* desc);
 
 /* Number of visible HIP devices (0 when there is none); never fails. */
 int  pt_device_count(void);
+
+/* ---- device plumbing for hosts without a HIP binding of their own ------------------------ */
+/* The reference does the same with cudaMalloc / cudaMemcpy / cudaDeviceSynchronize / cudaFree
+ * inline in main() (src/ptMain.cu:593-600,637,649-652). */
+int  pt_set_device(int device);
+int  pt_device_synchronize(void);
+int  pt_device_malloc(size_t bytes, void** out_device_ptr);
+void pt_device_free(void* device_ptr);
+int  pt_memcpy_to_host(void* host_dst, const void* device_src, size_t bytes);
+
+/* ---- one-node multi-GPU frame exchange over RCCL ------------------------------------------ */
+/* No counterpart in the reference (single device, no communication library).  One process per
+ * GPU: every rank renders its shard with pt_render_device (shard_index = rank, shard_count =
+ * world) into a zero-filled full frame, then pt_comm_reduce_frame sums the frames onto `root`
+ * over xGMI.  Each pixel is non-zero on exactly one rank, so the sum reproduces the
+ * single-GPU frame bit for bit.  id128 is RCCL's 128-byte unique id: rank 0 creates it and the
+ * host distributes it to the other ranks by any means before pt_comm_init. */
+typedef struct PtComm PtComm;
+int  pt_comm_unique_id(void* id128);
+int  pt_comm_init(const void* id128, int rank, int world, PtComm** out_comm);
+int  pt_comm_reduce_frame(PtComm* comm, void* d_frame, size_t n_floats, int root, void* hip_stream);
+void pt_comm_destroy(PtComm* comm);
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* Evaluates one of the library's libm replacements on n floats: fn 0 sin, 1 cos, 2 log, 3 x^5
+ * (the reference's Sin/Cos/Log/Pow wrappers, include/ptMath.h:34-45).  on_device != 0 runs the
+ * device code on the current HIP device, otherwise the same source compiled for the host. */
+int  pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device);
 
 #ifdef __cplusplus
 }

@@ -1021,3 +1021,17 @@ uint64_t oracle_fnv1a(const void* data, size_t n_bytes)
     for (size_t i = 0; i < n_bytes; i++) { h ^= p[i]; h *= 0x100000001b3ULL; }
     return h;
 }
+
+/* The host libm the reference's Sin/Cos/Log/Pow wrappers resolve to (include/ptMath.h:34-45):
+ * fn 0 sinf, 1 cosf, 2 logf, 3 powf(x, 5). */
+void oracle_libm(int fn, const float* x, size_t n, float* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = sinf(x[i]); break;
+        case 1: out[i] = cosf(x[i]); break;
+        case 2: out[i] = logf(x[i]); break;
+        default: out[i] = powf(x[i], 5); break;
+        }
+    }
+}

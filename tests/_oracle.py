@@ -26,6 +26,7 @@ class Oracle:
         lib.oracle_noise.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.oracle_texture_values.argtypes = [P(A.PtSceneDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         lib.oracle_aabb_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        lib.oracle_libm.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.oracle_fnv1a.argtypes = [C.c_void_p, C.c_size_t]
         lib.oracle_fnv1a.restype = C.c_uint64
 
@@ -91,6 +92,12 @@ class Oracle:
         self.lib.oracle_aabb_hits(boxes.ctypes.data, rays.ctypes.data, n, tmin, tmax, out.ctypes.data)
         return out
 
+    def libm(self, fn, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self.lib.oracle_libm(fn, x.ctypes.data, x.size, out.ctypes.data)
+        return out
+
     def fnv1a(self, arr):
         arr = np.ascontiguousarray(arr)
         return int(self.lib.oracle_fnv1a(arr.ctypes.data, arr.nbytes))
@@ -100,7 +107,8 @@ def load():
     global _LIB
     if _LIB is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        if not os.path.exists(path):
+        src = os.path.join(ORACLE_DIR, "pt_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", ORACLE_DIR])
         _LIB = Oracle(C.CDLL(path))
     return _LIB
