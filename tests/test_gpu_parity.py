@@ -108,7 +108,7 @@ def test_triangle_mesh_bit_exact(oracle, accel):
     ids_o, t_o = oracle.trace_closest(d, rays)
     ids_g, t_g = sc.trace_closest(rays)
     tri_hits = np.array([d.c.shapes[i].type == abi.SHAPE_TRIANGLE for i in ids_o[ids_o >= 0]]).sum()
-    assert tri_hits > 1000
+    assert tri_hits > 100        # few: the un-normalised triangle t (t_true * det) loses to the walls, as in the reference
     np.testing.assert_array_equal(ids_g, ids_o)
     np.testing.assert_array_equal(bits(t_g), bits(t_o))
     assert_bit_exact(sc.render(48, 48, 4), oracle.render(d, 48, 48, 4), "trimesh")
