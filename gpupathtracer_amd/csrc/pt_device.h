@@ -130,13 +130,17 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Pcg& g)
     const float phi = g.rand() * 2 * PI_F;
     const float z = 1 - 2 * g.rand();
     const float r = sqrtf(fmaxf(0.0f, 1 - z * z));
-    return mk(r * ptm::cosf_glibc(phi), r * ptm::sinf_glibc(phi), z);
+    float sn, cs;
+    ptm::sincosf_glibc(phi, &sn, &cs);
+    return mk(r * cs, r * sn, z);
 }
 __device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
 {
     const float r = sqrtf(g.rand());
     const float theta = g.rand() * 2 * PI_F;
-    return mk(r * ptm::cosf_glibc(theta), r * ptm::sinf_glibc(theta), 0.0f);
+    float sn, cs;
+    ptm::sincosf_glibc(theta, &sn, &cs);
+    return mk(r * cs, r * sn, 0.0f);
 }
 __device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
 {
@@ -144,8 +148,10 @@ __device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
     float r2 = g.rand();
     float z = sqrtf(1 - r2);
     float phi = 2 * PI_F * r1;
-    float x = ptm::cosf_glibc(phi) * 2 * sqrtf(r2);
-    float y = ptm::sinf_glibc(phi) * 2 * sqrtf(r2);
+    float sn, cs;
+    ptm::sincosf_glibc(phi, &sn, &cs);
+    float x = cs * 2 * sqrtf(r2);
+    float y = sn * 2 * sqrtf(r2);
     return mk(x, y, z);
 }
 __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqrd, Pcg& g)
@@ -154,8 +160,10 @@ __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqr
     float r2 = g.rand();
     float z = 1 + r2 * (sqrtf(1 - radius * radius / dist_sqrd) - 1);
     float phi = 2 * PI_F * r1;
-    float x = ptm::cosf_glibc(phi) * sqrtf(1 - z * z);
-    float y = ptm::sinf_glibc(phi) * sqrtf(1 - z * z);
+    float sn, cs;
+    ptm::sincosf_glibc(phi, &sn, &cs);
+    float x = cs * sqrtf(1 - z * z);
+    float y = sn * sqrtf(1 - z * z);
     return mk(x, y, z);
 }
 
@@ -179,10 +187,23 @@ __device__ __forceinline__ Ray camera_ray(const SceneView& sv, float s, float t,
     const V3 origin = mk(c[0], c[1], c[2]), llc = mk(c[3], c[4], c[5]);
     const V3 horiz = mk(c[6], c[7], c[8]), vert = mk(c[9], c[10], c[11]);
     const V3 cu = mk(c[12], c[13], c[14]), cv = mk(c[15], c[16], c[17]);
+    Ray r;
+    if (c[23] == 0.0f && c[0] != 0.0f && c[1] != 0.0f && c[2] != 0.0f) {
+        // Pinhole: the lens offset is 0 * (r cos, r sin) = (+-0, +-0).  Adding a signed zero to a
+        // non-zero origin, or subtracting it from a direction that is not -0 (a difference of
+        // finite terms never is), changes no bit, so the disk sample's sin/cos are not needed.
+        // Its two random numbers are still drawn.
+        (void)g.rand();
+        (void)g.rand();
+        float time = c[21] + g.rand() * (c[22] - c[21]);
+        r.o = origin;
+        r.d = llc + s * horiz + t * vert - origin;
+        r.time = time;
+        return r;
+    }
     V3 rd = c[23] * random_in_unit_disk(g);
     V3 offset = cu * rd.x + cv * rd.y;
     float time = c[21] + g.rand() * (c[22] - c[21]);
-    Ray r;
     r.o = origin + offset;
     r.d = llc + s * horiz + t * vert - origin - offset;
     r.time = time;

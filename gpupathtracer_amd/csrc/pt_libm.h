@@ -136,6 +136,32 @@ PT_HD float cosf_glibc(float y)
     return y - y;
 }
 
+
+// sinf_glibc(y) and cosf_glibc(y) with one shared range reduction; the two results are the same
+// bits as the separate calls (both evaluate their polynomial on the same reduced argument).
+PT_HD void sincosf_glibc(float y, float* sp, float* cp)
+{
+    double x = y;
+    int n;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) { *sp = y; *cp = 1.0f; return; }
+        const double x2 = x * x;
+        *sp = sincos_poly(x, x2, false, 0);
+        *cp = sincos_poly(x, x2, false, 1);
+    } else if (abstop12(y) < 0x7f8) {
+        int q;
+        if (abstop12(y) < abstop12(120.0f)) { x = reduce_fast(x, &n); q = n; }
+        else { const uint32_t xi = f2u(y); x = reduce_large(xi, &n); q = n + (int)(xi >> 31); }
+        const double s = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;
+        const bool neg = (q & 2) != 0;
+        const double xs = x * s, x2 = x * x;
+        *sp = sincos_poly(xs, x2, neg, n);
+        *cp = sincos_poly(xs, x2, neg, n ^ 1);
+    } else {
+        *sp = y - y; *cp = y - y;
+    }
+}
+
 PT_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 PT_HD uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 PT_HD double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
