@@ -18,35 +18,12 @@
 #include "pt_device.h"
 #include "pt_host.h"
 #include "pt_lbvh.h"
+#include "pt_internal.h"
 
 using namespace ptd;
+using namespace ptk;
 
 // ---- kernels ----------------------------------------------------------------------------------------
-
-struct RenderArgs {
-    int32_t nx, ny, ns, max_depth;
-    int32_t shard_index, shard_count;
-    int32_t tile_w, tile_h;        // shard tile size in pixels
-    int32_t tiles_x;               // tiles per image row
-    int32_t n_tiles;               // all tiles of the image
-    int32_t sub_x, sub_y;          // 8x8 wave tiles per shard tile
-    int32_t n_wave_tiles;          // wave tiles owned by this shard
-};
-
-// Wave w of the launch -> its 8x8 pixel block.  Shard tiles owned by this shard are
-// tile = shard_index + k * shard_count; each is cut into sub_x * sub_y wave tiles.
-__device__ __forceinline__ bool wave_pixel(const RenderArgs& ra, int wave, int lane, int& x, int& ytop)
-{
-    const int per_tile = ra.sub_x * ra.sub_y;
-    const int k = wave / per_tile, sub = wave - k * per_tile;
-    const int tile = ra.shard_index + k * ra.shard_count;
-    const int ty = tile / ra.tiles_x, tx = tile - ty * ra.tiles_x;
-    const int sy = sub / ra.sub_x, sx = sub - sy * ra.sub_x;
-    const int lx = sx * 8 + (lane & 7), ly = sy * 8 + (lane >> 3);
-    x = tx * ra.tile_w + lx;
-    ytop = ty * ra.tile_h + ly;
-    return lx < ra.tile_w && ly < ra.tile_h && x < ra.nx && ytop < ra.ny;
-}
 
 template <uint32_t F>
 __global__ __launch_bounds__(256) void k_render_fused(SceneView sv, RenderArgs ra, float* __restrict__ out)
@@ -134,13 +111,6 @@ __global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay
 
 namespace {
 
-constexpr uint32_t M_CORNELL = F_RECT | F_BOX | F_XFORM | F_LIGHTS;
-constexpr uint32_t M_SPHERES = F_SPHERE | F_MSPHERE | F_METAL | F_DIELECTRIC | F_CHECKER | F_SKY;
-constexpr uint32_t M_SPHERES_LBVH = M_SPHERES | F_LBVH;
-constexpr uint32_t M_TRIMESH = F_RECT | F_TRIANGLE | F_LIGHTS | F_LBVH;
-constexpr uint32_t M_ALL = F_ALL & ~F_LBVH;
-constexpr uint32_t M_ALL_LBVH = F_ALL;
-
 const uint32_t k_masks[] = { M_CORNELL, M_SPHERES, M_SPHERES_LBVH, M_TRIMESH, M_ALL, M_ALL_LBVH };
 
 int pick_variant(uint32_t scene_mask)
@@ -181,20 +151,6 @@ void launch_trace(int variant, const SceneView& sv, const PtRay* rays, size_t n,
 }  // namespace
 
 // ---- host side of the C ABI --------------------------------------------------------------------------
-
-struct PtScene {
-    int device = 0;
-    SceneView view{};
-    std::vector<void*> allocs;          // every device allocation of this scene
-    uint32_t mask = 0;
-    int variant = -1;
-    int n_shapes = 0, n_media = 0;
-    int lbvh_nodes = 0;
-    // timing of the most recent render
-    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
-    bool have_timing = false;
-    PtRenderStats last{};
-};
 
 namespace {
 
@@ -436,21 +392,26 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (p->pipeline != PT_PIPELINE_DEFAULT && p->pipeline != PT_PIPELINE_FUSED && p->pipeline != PT_PIPELINE_WAVEFRONT) {
         pt::set_error("render: unknown pipeline"); return PT_ERR_INVALID;
     }
-    if (p->pipeline == PT_PIPELINE_WAVEFRONT) { pt::set_error("render: the wavefront scheduler is not available in this build"); return PT_ERR_UNSUPPORTED; }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
     if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
     // pixels this shard does not own must read as zero so that shards sum to the frame
     if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
-    if (ra.n_wave_tiles > 0) launch_render(sc->variant, sc->view, ra, out, st);
-    if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
+    sc->last = PtRenderStats{};
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT) {
+        const int rc = pt::render_wavefront(sc, ra, out, st);       // host-driven rounds; blocks
+        if (rc != PT_OK) return rc;
+        sc->last.pipeline = PT_PIPELINE_WAVEFRONT;
+    } else {
+        if (ra.n_wave_tiles > 0) launch_render(sc->variant, sc->view, ra, out, st);
+        if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
+        sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
+        sc->last.pipeline = PT_PIPELINE_FUSED;
+    }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->have_timing = true;
-    sc->last = PtRenderStats{};
-    sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
-    sc->last.pipeline = PT_PIPELINE_FUSED;
     // paths = owned pixels x ns
     uint64_t owned_px = 0;
     {

@@ -1,0 +1,71 @@
+// Declarations shared by the translation units that implement the C ABI.
+#ifndef PT_INTERNAL_H
+#define PT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "pt_device.h"
+
+struct RenderArgs {
+    int32_t nx, ny, ns, max_depth;
+    int32_t shard_index, shard_count;
+    int32_t tile_w, tile_h;        // shard tile size in pixels
+    int32_t tiles_x;               // tiles per image row
+    int32_t n_tiles;               // all tiles of the image
+    int32_t sub_x, sub_y;          // 8x8 wave tiles per shard tile
+    int32_t n_wave_tiles;          // wave tiles owned by this shard
+};
+
+// Wave w of the launch -> its 8x8 pixel block.  Shard tiles owned by this shard are
+// tile = shard_index + k * shard_count; each is cut into sub_x * sub_y wave tiles.
+static __device__ __forceinline__ bool wave_pixel(const RenderArgs& ra, int wave, int lane, int& x, int& ytop)
+{
+    const int per_tile = ra.sub_x * ra.sub_y;
+    const int k = wave / per_tile, sub = wave - k * per_tile;
+    const int tile = ra.shard_index + k * ra.shard_count;
+    const int ty = tile / ra.tiles_x, tx = tile - ty * ra.tiles_x;
+    const int sy = sub / ra.sub_x, sx = sub - sy * ra.sub_x;
+    const int lx = sx * 8 + (lane & 7), ly = sy * 8 + (lane >> 3);
+    x = tx * ra.tile_w + lx;
+    ytop = ty * ra.tile_h + ly;
+    return lx < ra.tile_w && ly < ra.tile_h && x < ra.nx && ytop < ra.ny;
+}
+
+
+// Kernel specialisations by feature mask; a scene runs on the first one that covers it.
+namespace ptk {
+using namespace ptd;
+constexpr uint32_t M_CORNELL = F_RECT | F_BOX | F_XFORM | F_LIGHTS;
+constexpr uint32_t M_SPHERES = F_SPHERE | F_MSPHERE | F_METAL | F_DIELECTRIC | F_CHECKER | F_SKY;
+constexpr uint32_t M_SPHERES_LBVH = M_SPHERES | F_LBVH;
+constexpr uint32_t M_TRIMESH = F_RECT | F_TRIANGLE | F_LIGHTS | F_LBVH;
+constexpr uint32_t M_ALL = F_ALL & ~F_LBVH;
+constexpr uint32_t M_ALL_LBVH = F_ALL;
+
+constexpr int N_VARIANTS = 6;
+}  // namespace ptk
+
+struct PtScene {
+    int device = 0;
+    ptd::SceneView view{};
+    std::vector<void*> allocs;          // every device allocation of this scene
+    uint32_t mask = 0;
+    int variant = -1;
+    int n_shapes = 0, n_media = 0;
+    int lbvh_nodes = 0;
+    // timing of the most recent render
+    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+    bool have_timing = false;
+    PtRenderStats last{};
+};
+
+
+namespace pt {
+// Staged (wavefront) scheduler, pt_wavefront.hip.  Blocks until the frame is complete.
+int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_t st);
+}
+
+#endif
