@@ -1,0 +1,121 @@
+// Command-line host: the reference's main() (src/ptMain.cu:500-698) over the C ABI.
+//
+// Same flags and defaults as the reference (src/ptMain.cu:502-549): -q/--quick, -c/--cpu,
+// -m/--median, -w/--width, -h/--height (height, not help), -n/--numsamples, -t/--threads,
+// -d/--maxdepth, -s/--stacksize, -f/--file; plus --scene, --gpus, --accel, --pipeline, which the
+// reference lacks (its scene is a source edit at src/ptMain.cu:559).  The reference parses with
+// the vendored cxxopts; getopt_long gives the same short/long spellings here.
+#include <getopt.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/ptcore.h"
+#include "pt_image_io.h"
+
+namespace {
+
+int fail(const char* what)
+{
+    std::cerr << what << ": " << pt_last_error() << std::endl;
+    return EXIT_FAILURE;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    bool quick = false, cpu = false, median = false;
+    int ns = 100, nx = 128 * 4, ny = 128 * 4, maxDepth = 25, gpus = 1;
+    std::string outFile = "outputImage.ppm", scene = "random", accel = "auto", pipeline = "fused";
+
+    static const option longopts[] = {
+        { "quick", no_argument, nullptr, 'q' }, { "cpu", no_argument, nullptr, 'c' }, { "median", no_argument, nullptr, 'm' },
+        { "width", required_argument, nullptr, 'w' }, { "height", required_argument, nullptr, 'h' },
+        { "numsamples", required_argument, nullptr, 'n' }, { "threads", required_argument, nullptr, 't' },
+        { "maxdepth", required_argument, nullptr, 'd' }, { "stacksize", required_argument, nullptr, 's' },
+        { "file", required_argument, nullptr, 'f' }, { "scene", required_argument, nullptr, 1000 },
+        { "gpus", required_argument, nullptr, 1001 }, { "accel", required_argument, nullptr, 1002 },
+        { "pipeline", required_argument, nullptr, 1003 }, { nullptr, 0, nullptr, 0 } };
+    int c;
+    while ((c = getopt_long(argc, argv, "qcmw:h:n:t:d:s:f:", longopts, nullptr)) != -1) {
+        switch (c) {
+        case 'q': quick = true; break;
+        case 'c': cpu = true; break;
+        case 'm': median = true; break;
+        case 'w': nx = std::atoi(optarg); break;
+        case 'h': ny = std::atoi(optarg); break;
+        case 'n': ns = std::atoi(optarg); break;
+        case 't': break;                         // render threads: host-loop option, nothing to do on the GPU path
+        case 'd': maxDepth = std::atoi(optarg); break;
+        case 's': break;                         // GPU thread stack size: the kernels do not recurse
+        case 'f': outFile = optarg; break;
+        case 1000: scene = optarg; break;
+        case 1001: gpus = std::atoi(optarg); break;
+        case 1002: accel = optarg; break;
+        case 1003: pipeline = optarg; break;
+        default:
+            std::cerr << "usage: ptrace [-q] [-w W] [-h H] [-n SPP] [-d DEPTH] [-f out.{ppm,hdr,png,tga,bmp}]\n"
+                         "              [--scene simple_spheres|simple_light|random|cornell|cornell_spheres|final|trimesh]\n"
+                         "              [--gpus N] [--accel auto|list|lbvh] [--pipeline fused|wavefront]" << std::endl;
+            return EXIT_FAILURE;
+        }
+    }
+    if (cpu) { std::cerr << "-c/--cpu: this build renders on the GPU only; it has no CPU path." << std::endl; return EXIT_FAILURE; }
+    if (median) std::cerr << "-m/--median: the median post-filter is not part of this build; writing the unfiltered image." << std::endl;
+    if (quick) { nx /= 8; ny /= 8; ns /= 16; }   // src/ptMain.cu:544-549
+    if (nx <= 0 || ny <= 0 || ns <= 0 || gpus <= 0) { std::cerr << "width, height, numsamples and gpus must be positive" << std::endl; return EXIT_FAILURE; }
+
+    const float aspect = float(nx) / float(ny);
+    PtSceneDesc* desc = nullptr;
+    if (pt_scene_desc_builtin(scene.c_str(), aspect, nullptr, 0, 0, &desc) != PT_OK) return fail("scene");
+    if (accel == "lbvh") desc->accel = PT_ACCEL_LBVH;
+    else if (accel == "list") desc->accel = PT_ACCEL_LIST;
+    else if (desc->n_world > 32 && desc->n_media == 0 && desc->n_bvhs == 0) desc->accel = PT_ACCEL_LBVH;
+
+    const int have = pt_device_count();
+    if (have < 1) { std::cerr << "no HIP device is visible" << std::endl; return EXIT_FAILURE; }
+    if (gpus > have) { std::cerr << "--gpus " << gpus << " but only " << have << " device(s) visible" << std::endl; return EXIT_FAILURE; }
+
+    PtRenderParams p{};
+    p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = maxDepth; p.shard_count = gpus; p.tile_w = 8; p.tile_h = 8;
+    p.pipeline = (pipeline == "wavefront") ? PT_PIPELINE_WAVEFRONT : PT_PIPELINE_FUSED;
+
+    std::cerr << "Allocating world...";
+    std::vector<PtScene*> scenes((size_t)gpus, nullptr);
+    std::vector<void*> frames((size_t)gpus, nullptr);
+    const size_t n_floats = (size_t)3 * nx * ny;
+    for (int g = 0; g < gpus; g++) {
+        if (pt_set_device(g) != PT_OK) return fail("set device");
+        if (pt_scene_create(desc, &scenes[(size_t)g]) != PT_OK) return fail("\nFailed to allocate world in GPU memory");
+        if (pt_device_malloc(n_floats * sizeof(float), &frames[(size_t)g]) != PT_OK) return fail("frame buffer");
+    }
+    std::cerr << "done" << std::endl << "Rendering world...";
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int g = 0; g < gpus; g++) {             // every device traces its tile shard concurrently
+        if (pt_set_device(g) != PT_OK) return fail("set device");
+        p.shard_index = g;
+        if (pt_render_device(scenes[(size_t)g], &p, frames[(size_t)g], nullptr) != PT_OK) return fail("\nFailed to render on GPU");
+    }
+    std::vector<float> image(n_floats, 0.0f), part(n_floats);
+    for (int g = 0; g < gpus; g++) {
+        if (pt_set_device(g) != PT_OK || pt_device_synchronize() != PT_OK) return fail("\nFailed to render on GPU");
+        if (pt_memcpy_to_host(part.data(), frames[(size_t)g], n_floats * sizeof(float)) != PT_OK) return fail("copy back");
+        for (size_t i = 0; i < n_floats; i++) image[i] += part[i];    // shards are disjoint: x + 0 = x
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cerr << "done" << std::endl;
+    std::cerr << (double)nx * ny * ns / sec / 1e6 << " Mpaths/s (" << sec << " s, " << gpus << " GPU)" << std::endl;
+    for (int g = 0; g < gpus; g++) { pt_set_device(g); pt_device_free(frames[(size_t)g]); pt_scene_destroy(scenes[(size_t)g]); }
+    pt_scene_desc_free(desc);
+
+    std::string err;
+    if (!pt::write_image(outFile, image.data(), nx, ny, &err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }
+    std::cerr << "Done." << std::endl;
+    return EXIT_SUCCESS;
+}

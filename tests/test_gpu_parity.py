@@ -223,3 +223,27 @@ def test_wavefront_scheduler_edge_cases(oracle):
     d2 = pt.builtin_scene("final", 16 / 9, earth_rgb=tex)
     sc2 = pt.Scene(d2)
     assert_bit_exact(sc2.render(64, 36, 4, pipeline=abi.PIPELINE_WAVEFRONT), sc2.render(64, 36, 4), "wavefront final+image")
+
+
+def test_cli_writes_every_image_format(tmp_path, oracle):
+    """The C++ host (reference main()'s flags) renders through the C ABI and writes each format;
+    8-bit pixels must be Clamp(int(255.99*c),0,255) of the oracle's frame."""
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(HERE), "gpupathtracer_amd", "ptrace")
+    d = pt.builtin_scene("cornell", 48 / 32)
+    ref = oracle.render(d, 48, 32, 4)
+    want8 = np.clip((255.99 * ref.astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)
+    for ext in ("ppm", "png", "tga", "bmp", "hdr"):
+        out = str(tmp_path / ("img." + ext))
+        r = subprocess.run([exe, "--scene", "cornell", "-w", "48", "-h", "32", "-n", "4", "-f", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        if ext == "hdr":
+            assert open(out, "rb").read(10) == b"#?RADIANCE"
+            continue
+        got = np.asarray(Image.open(out).convert("RGB"))
+        np.testing.assert_array_equal(got, want8)
+    r = subprocess.run([exe, "--scene", "cornell", "-c"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU path" in r.stderr
+    r = subprocess.run([exe, "--scene", "nope", "-q"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown scene" in r.stderr
