@@ -11,6 +11,7 @@ OBJ_SHAPE, OBJ_MEDIUM, OBJ_BVH = 1, 2, 3
 AMBIENT_NONE, AMBIENT_CONSTANT, AMBIENT_SKY = 0, 1, 2
 ACCEL_LIST, ACCEL_LBVH = 0, 1
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
+SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL = 0, 1, 2
 ID_MISS = -1
 ID_MEDIUM_BASE = 0x40000000
 
@@ -81,7 +82,7 @@ class PtRenderParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("ns", C.c_int32), ("max_depth", C.c_int32),
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32),
-                ("pipeline", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("pipeline", C.c_int32), ("schedule", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class PtRay(C.Structure):

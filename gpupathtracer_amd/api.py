@@ -206,9 +206,9 @@ class RenderStats:
         self.paths = int(s.paths)
 
 
-def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0):
+def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0):
     return A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=shard_index,
-                            shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline)
+                            shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline, schedule=schedule)
 
 
 class Scene:

@@ -2,7 +2,7 @@
 //
 // The reference's device side is one megakernel, one thread per pixel, all samples and bounces
 // in nested loops behind virtual calls (render_kernel, src/ptMain.cu:171-190).  Here:
-//   * k_render_fused: one lane per pixel, one loop iteration per BOUNCE; a lane whose path ended
+//   * k_render_tiles / k_render_refill: one lane per pixel, one loop iteration per BOUNCE; a lane whose path ended
 //     accumulates it and regenerates the next camera sample inside the same loop, so the 64 lanes
 //     of a wave stay busy although their paths have different lengths.  The pixel's PCG stream is
 //     carried in registers across samples and bounces exactly as render_pixel does
@@ -25,8 +25,85 @@ using namespace ptk;
 
 // ---- kernels ----------------------------------------------------------------------------------------
 
+// One lane's path tracer state: the pixel's random stream, its running sum and the path in flight.
+struct LaneState {
+    Pcg rng;
+    V3 accum, thr;
+    Ray ray;
+    int x, y;             // render_kernel's pixel coordinates (y counts up from the bottom row)
+    int s, depth;
+    bool fresh;           // the next step starts a new camera sample
+};
+
+__device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs& ra, int x, int ytop, unsigned& i)
+{
+    st.x = x;
+    st.y = ra.ny - 1 - ytop;                              // row 0 of the image is the top
+    i = (unsigned)(ytop * ra.nx + x);                     // = (ny - y - 1) * nx + x   (src/ptMain.cu:178)
+    st.rng.seed(i);                                       // PcgRng rng(i)              (src/ptMain.cu:183)
+    st.accum = mk(0, 0, 0);
+    st.s = 0;
+    st.fresh = true;
+}
+
+// One bounce of the pixel's sample loop.  Returns true when the pixel's last sample has ended.
 template <uint32_t F>
-__global__ __launch_bounds__(256) void k_render_fused(SceneView sv, RenderArgs ra, float* __restrict__ out)
+__device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, float fnx, float fny,
+                                          int* my_stack)
+{
+    if (st.fresh) {                                       // render_pixel, src/ptMain.cu:158-160
+        float u = ((float)st.x + st.rng.rand()) / fnx;
+        float v = ((float)st.y + st.rng.rand()) / fny;
+        st.ray = camera_ray(sv, u, v, st.rng);
+        st.thr = mk(1, 1, 1);
+        st.depth = 0;
+        st.fresh = false;
+    }
+    bool ended;
+    if (st.depth >= ra.max_depth) {
+        ended = true;                                     // bounce limit: color() returns the running product
+    } else {
+        Hit h;
+        if (world_hit<F>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack)) {
+            ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
+        } else {
+            shade_miss<F>(sv, st.ray, st.thr);
+            ended = true;
+        }
+        st.depth++;
+    }
+    if (ended) {                                          // accumCol += deNan(color(...)), src/ptMain.cu:46-53,161
+        if (!(st.thr.x == st.thr.x)) st.thr.x = 0;
+        if (!(st.thr.y == st.thr.y)) st.thr.y = 0;
+        if (!(st.thr.z == st.thr.z)) st.thr.z = 0;
+        st.accum = st.accum + st.thr;
+        st.s++;
+        st.fresh = true;
+        return st.s >= ra.ns;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void lane_write_pixel(const LaneState& st, const RenderArgs& ra, unsigned i, float* __restrict__ out)
+{
+    const float inv_ns = 1 / (float)ra.ns;                // accumCol /= float(ns): reciprocal, then multiplies
+    out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, st.accum.x * inv_ns));
+    out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, st.accum.y * inv_ns));
+    out[3 * (size_t)i + 2] = sqrtf(fmaxf(0.0f, st.accum.z * inv_ns));
+}
+
+__device__ __forceinline__ void lane_init(LaneState& st)
+{
+    st.rng.state = 0; st.rng.inc = 1;
+    st.accum = mk(0, 0, 0); st.thr = mk(1, 1, 1);
+    st.ray.o = mk(0, 0, 0); st.ray.d = mk(0, 0, 1); st.ray.time = 0;
+    st.x = 0; st.y = 0; st.s = 0; st.depth = 0; st.fresh = true;
+}
+
+// Fused scheduler, one 8x8 tile per wave and one pixel per lane.  The lanes of a wave start in
+// phase, which keeps the shading branches less divergent when shading dominates a bounce.
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
 {
     __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const int lane = threadIdx.x & 63;
@@ -36,55 +113,54 @@ __global__ __launch_bounds__(256) void k_render_fused(SceneView sv, RenderArgs r
     int x, ytop;
     if (!wave_pixel(ra, wave, lane, x, ytop)) return;
     int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-
-    const int y = ra.ny - 1 - ytop;                       // render_kernel's y: row 0 of the image is the top
-    const unsigned i = (unsigned)(ytop * ra.nx + x);      // = (ny - y - 1) * nx + x   (src/ptMain.cu:178)
-    Pcg rng;
-    rng.seed(i);                                          // PcgRng rng(i)              (src/ptMain.cu:183)
-
     const float fnx = (float)ra.nx, fny = (float)ra.ny;
-    V3 accum = mk(0, 0, 0);
-    V3 thr = mk(1, 1, 1);
-    Ray ray;
-    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.time = 0;
-    int s = 0, depth = 0;
-    bool fresh = true;
-    while (s < ra.ns) {
-        if (fresh) {                                      // render_pixel, src/ptMain.cu:158-160
-            float u = ((float)x + rng.rand()) / fnx;
-            float v = ((float)y + rng.rand()) / fny;
-            ray = camera_ray(sv, u, v, rng);
-            thr = mk(1, 1, 1);
-            depth = 0;
-            fresh = false;
+    LaneState st;
+    lane_init(st);
+    unsigned i;
+    lane_begin_pixel(st, ra, x, ytop, i);
+    while (!lane_step<F>(sv, ra, st, fnx, fny, my_stack)) {}
+    lane_write_pixel(st, ra, i, out);
+}
+
+// Fused scheduler with persistent lanes: a lane that has finished its pixel takes the next pixel
+// slot of the shard (slots are numbered tile by tile, 64 per 8x8 wave tile) from a device counter,
+// so a wave stays full until the shard runs out.  Pays when the closest-hit search, whose loop is
+// uniform over the wave, dominates a bounce.  Which lane traces a pixel does not matter: the
+// pixel's random stream is seeded by its index (src/ptMain.cu:178-184).
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
+                                                       unsigned* __restrict__ next_slot)
+{
+    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+    const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
+    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    LaneState st;
+    lane_init(st);
+    unsigned i = 0;
+    bool have = false;
+    while (true) {
+        if (!have) {
+            const unsigned long long need = __ballot(1);  // one atomic per wave for all lanes that ran dry
+            const int leader = __ffsll((long long)need) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(next_slot, (unsigned)__popcll(need));
+            base = __shfl(base, leader);
+            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const unsigned slot = base + (unsigned)__popcll(need & lower);
+            if (slot >= total_slots) break;               // the shard is exhausted: this lane is done
+            int x, ytop;
+            if (!wave_pixel(ra, (int)(slot >> 6), (int)(slot & 63), x, ytop)) continue;   // slot beyond the image edge
+            lane_begin_pixel(st, ra, x, ytop, i);
+            have = true;
         }
-        bool ended;
-        if (depth >= ra.max_depth) {
-            ended = true;                                 // bounce limit: color() returns the running product
-        } else {
-            Hit h;
-            if (world_hit<F>(sv, ray, 0.001f, FLT_MAX, h, rng, my_stack)) {
-                ended = !shade<F>(sv, ray, h, thr, rng);
-            } else {
-                shade_miss<F>(sv, ray, thr);
-                ended = true;
-            }
-            depth++;
-        }
-        if (ended) {                                      // accumCol += deNan(color(...)), src/ptMain.cu:46-53,161
-            if (!(thr.x == thr.x)) thr.x = 0;
-            if (!(thr.y == thr.y)) thr.y = 0;
-            if (!(thr.z == thr.z)) thr.z = 0;
-            accum = accum + thr;
-            s++;
-            fresh = true;
+        if (lane_step<F>(sv, ra, st, fnx, fny, my_stack)) {
+            lane_write_pixel(st, ra, i, out);
+            have = false;
         }
     }
-    const float inv_ns = 1 / (float)ra.ns;                // accumCol /= float(ns): reciprocal, then multiplies
-    accum = mk(accum.x * inv_ns, accum.y * inv_ns, accum.z * inv_ns);
-    out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, accum.x));
-    out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, accum.y));
-    out[3 * (size_t)i + 2] = sqrtf(fmaxf(0.0f, accum.z));
 }
 
 template <uint32_t F>
@@ -122,16 +198,19 @@ int pick_variant(uint32_t scene_mask)
     return -1;
 }
 
-void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, hipStream_t st)
+void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
 {
-    const dim3 block(256), grid((ra.n_wave_tiles + 3) / 4);
+    // REFILL: persistent grid of at most 32 waves per CU, the rest of the shard comes from the counter.
+    const bool refill = ra.refill != 0;
+    const int tiles4 = (ra.n_wave_tiles + 3) / 4;
+    const dim3 block(256), grid(refill ? std::min(tiles4, 2048) : tiles4);
     switch (variant) {
-    case 0: hipLaunchKernelGGL(k_render_fused<M_CORNELL>, grid, block, 0, st, sv, ra, out); break;
-    case 1: hipLaunchKernelGGL(k_render_fused<M_SPHERES>, grid, block, 0, st, sv, ra, out); break;
-    case 2: hipLaunchKernelGGL(k_render_fused<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, out); break;
-    case 3: hipLaunchKernelGGL(k_render_fused<M_TRIMESH>, grid, block, 0, st, sv, ra, out); break;
-    case 4: hipLaunchKernelGGL(k_render_fused<M_ALL>, grid, block, 0, st, sv, ra, out); break;
-    default: hipLaunchKernelGGL(k_render_fused<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out); break;
+    case 0: if (refill) hipLaunchKernelGGL(k_render_refill<M_CORNELL>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_CORNELL>, grid, block, 0, st, sv, ra, out); break;
+    case 1: if (refill) hipLaunchKernelGGL(k_render_refill<M_SPHERES>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_SPHERES>, grid, block, 0, st, sv, ra, out); break;
+    case 2: if (refill) hipLaunchKernelGGL(k_render_refill<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, out); break;
+    case 3: if (refill) hipLaunchKernelGGL(k_render_refill<M_TRIMESH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_TRIMESH>, grid, block, 0, st, sv, ra, out); break;
+    case 4: if (refill) hipLaunchKernelGGL(k_render_refill<M_ALL>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_ALL>, grid, block, 0, st, sv, ra, out); break;
+    default: if (refill) hipLaunchKernelGGL(k_render_refill<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out); break;
     }
 }
 
@@ -343,6 +422,12 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     sc->mask = mask;
     sc->variant = pick_variant(mask);
     if (sc->variant < 0) { pt::set_error("pt_scene_create: no kernel specialisation covers this scene"); pt_scene_destroy(sc); return PT_ERR_UNSUPPORTED; }
+    {
+        void* ctr = nullptr;
+        if (!hip_ok(hipMalloc(&ctr, 256), "hipMalloc(slot counter)")) { pt_scene_destroy(sc); return PT_ERR_OOM; }
+        sc->allocs.push_back(ctr);
+        sc->next_slot = static_cast<unsigned*>(ctr);
+    }
     ok = hip_ok(hipEventCreate(&sc->ev_begin), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_k0), "hipEventCreate")
       && hip_ok(hipEventCreate(&sc->ev_k1), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_end), "hipEventCreate");
     if (!ok) { pt_scene_destroy(sc); return PT_ERR_HIP; }
@@ -379,6 +464,7 @@ bool make_args(const PtRenderParams* p, RenderArgs* ra)
     ra->sub_x = (tw + 7) / 8; ra->sub_y = (th + 7) / 8;
     const int owned = (ra->n_tiles - p->shard_index + sc - 1) / sc;     // tiles t with t % sc == shard_index
     ra->n_wave_tiles = owned * ra->sub_x * ra->sub_y;
+    ra->refill = 0;
     return true;
 }
 
@@ -392,6 +478,13 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (p->pipeline != PT_PIPELINE_DEFAULT && p->pipeline != PT_PIPELINE_FUSED && p->pipeline != PT_PIPELINE_WAVEFRONT) {
         pt::set_error("render: unknown pipeline"); return PT_ERR_INVALID;
     }
+    if (p->schedule != PT_SCHEDULE_AUTO && p->schedule != PT_SCHEDULE_TILES && p->schedule != PT_SCHEDULE_REFILL) {
+        pt::set_error("render: unknown schedule"); return PT_ERR_INVALID;
+    }
+    // Refilling keeps waves full but puts their lanes out of phase; that pays when a bounce is
+    // mostly the (wave-uniform) closest-hit search, not when shading dominates it.
+    ra.refill = (p->schedule == PT_SCHEDULE_REFILL) ||
+                (p->schedule == PT_SCHEDULE_AUTO && ((sc->mask & (ptd::F_LBVH | ptd::F_REFBVH)) || sc->view.n_world > 16));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
     if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
@@ -404,7 +497,8 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
         if (rc != PT_OK) return rc;
         sc->last.pipeline = PT_PIPELINE_WAVEFRONT;
     } else {
-        if (ra.n_wave_tiles > 0) launch_render(sc->variant, sc->view, ra, out, st);
+        if (!hip_ok(hipMemsetAsync(sc->next_slot, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
+        if (ra.n_wave_tiles > 0) launch_render(sc->variant, sc->view, ra, out, sc->next_slot, st);
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;

@@ -17,6 +17,7 @@ struct RenderArgs {
     int32_t n_tiles;               // all tiles of the image
     int32_t sub_x, sub_y;          // 8x8 wave tiles per shard tile
     int32_t n_wave_tiles;          // wave tiles owned by this shard
+    int32_t refill;                // fused scheduler: persistent lanes that pull pixel slots from a counter
 };
 
 // Wave w of the launch -> its 8x8 pixel block.  Shard tiles owned by this shard are
@@ -56,6 +57,7 @@ struct PtScene {
     int variant = -1;
     int n_shapes = 0, n_media = 0;
     int lbvh_nodes = 0;
+    unsigned* next_slot = nullptr;      // device counter of the fused scheduler's pixel-slot pool
     // timing of the most recent render
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
     bool have_timing = false;

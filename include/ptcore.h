@@ -90,6 +90,13 @@ enum PtPipeline {
     PT_PIPELINE_WAVEFRONT = 2  /* staged: generate / extend / shade (material-sorted) / light   */
 };
 
+/* How the fused scheduler hands pixels to lanes.  The image is the same either way. */
+enum PtSchedule {
+    PT_SCHEDULE_AUTO   = 0, /* REFILL when the closest-hit search dominates (a tree, or > 16 world objects) */
+    PT_SCHEDULE_TILES  = 1, /* one 8x8 tile per wave, one pixel per lane                                 */
+    PT_SCHEDULE_REFILL = 2  /* persistent lanes pull the next pixel from a device counter                */
+};
+
 /* Ids reported by pt_trace_closest. */
 #define PT_ID_MISS        (-1)
 #define PT_ID_MEDIUM_BASE 0x40000000   /* + index into media */
@@ -171,7 +178,8 @@ typedef struct PtRenderParams {
     int32_t shard_index, shard_count;
     int32_t tile_w, tile_h;
     int32_t pipeline;     /* PtPipeline */
-    int32_t reserved[7];
+    int32_t schedule;     /* PtSchedule (fused pipeline only) */
+    int32_t reserved[6];
 } PtRenderParams;
 
 /* One ray for pt_trace_closest.  The hit range is the integrator's [0.001, FLT_MAX]

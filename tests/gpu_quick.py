@@ -11,13 +11,21 @@ for name, aspect, nx, ny, ns in [("cornell", 1.0, 96, 96, 8), ("random", 2.0, 12
                                  ("cornell_spheres", 1.0, 64, 64, 8), ("simple_light", 2.0, 80, 40, 8), ("final", 16 / 9, 96, 54, 8)]:
     d = pt.builtin_scene(name, aspect)
     sc = pt.Scene(d)
-    img = sc.render(nx, ny, ns); ref = orc.render(d, nx, ny, ns, threads=16)
-    e = np.array_equal(img.view(np.uint32), ref.view(np.uint32)); ok &= e
+    ref = orc.render(d, nx, ny, ns, threads=16)
+    e = True
+    for sched in (1, 2):
+        img = sc.render(nx, ny, ns, schedule=sched)
+        e &= np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    ok &= e
     print("%-16s bit-exact %s" % (name, e), flush=True)
 d = pt.builtin_scene("cornell", 1.0); sc = pt.Scene(d)
 for ns in (64, 1024):
-    sc.render(1024, 1024, ns); st = sc.stats()
-    print("cornell 1024^2 x %d: %.2f ms  %.1f Mpaths/s" % (ns, st.kernel_ms, 1024 * 1024 * ns / st.kernel_ms / 1e3), flush=True)
+  for sched in (1, 2):
+    sc.render(1024, 1024, ns, schedule=sched); st = sc.stats()
+    print("cornell 1024^2 x %d sched %d: %.2f ms  %.1f Mpaths/s" % (ns, sched, st.kernel_ms, 1024 * 1024 * ns / st.kernel_ms / 1e3), flush=True)
+for sched in (1, 2):
+    sc.render(1024, 1024, 1024, shard_index=0, shard_count=8, schedule=sched)
+    print("1/8 shard sched %d: %.2f ms" % (sched, sc.stats().kernel_ms), flush=True)
 sc.render(1024, 1024, 1024, shard_index=0, shard_count=8); t8 = sc.stats().kernel_ms
 sc.render(1024, 1024, 1024); t1 = sc.stats().kernel_ms
 print("1/8 shard %.2f ms -> est. 8-GPU efficiency %.3f" % (t8, t1 / (8 * t8)), flush=True)

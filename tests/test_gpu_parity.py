@@ -45,9 +45,12 @@ def random_rays(rng, n, lo, hi):
 @pytest.mark.parametrize("name,aspect,nx,ny,ns", SCENES)
 def test_image_bit_exact(oracle, name, aspect, nx, ny, ns):
     d = pt.builtin_scene(name, aspect)
-    img = pt.Scene(d).render(nx, ny, ns)
+    sc = pt.Scene(d)
+    img = sc.render(nx, ny, ns)
     ref = oracle.render(d, nx, ny, ns)
     assert_bit_exact(img, ref, name)
+    for schedule in (abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):      # who traces a pixel never changes it
+        assert_bit_exact(sc.render(nx, ny, ns, schedule=schedule), ref, "%s schedule %d" % (name, schedule))
     gold = json.load(open(os.path.join(HERE, "golden", "oracle_hashes.json")))
     key = "%s|%r|%d|%d|%d" % (name, aspect, nx, ny, ns)
     if gold["glibc"] == os.confstr("CS_GNU_LIBC_VERSION"):
@@ -127,8 +130,11 @@ def test_final_scene_with_image_texture(oracle):
 @pytest.mark.parametrize("nx,ny,ns,depth", [(37, 21, 3, 25), (1, 1, 5, 25), (8, 8, 1, 25), (33, 9, 4, 0), (33, 9, 4, 1), (16, 16, 2, 3)])
 def test_ragged_sizes_and_depth_limits(oracle, nx, ny, ns, depth):
     d = pt.builtin_scene("cornell", nx / ny)
-    img = pt.Scene(d).render(nx, ny, ns, depth)
-    assert_bit_exact(img, oracle.render(d, nx, ny, ns, depth), "cornell %dx%d ns%d depth%d" % (nx, ny, ns, depth))
+    ref = oracle.render(d, nx, ny, ns, depth)
+    sc = pt.Scene(d)
+    for schedule in (abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
+        assert_bit_exact(sc.render(nx, ny, ns, depth, schedule=schedule), ref,
+                         "cornell %dx%d ns%d depth%d schedule %d" % (nx, ny, ns, depth, schedule))
 
 
 @pytest.mark.parametrize("shards,tile", [(2, (8, 8)), (3, (16, 8)), (8, (8, 8)), (5, (24, 40))])
@@ -139,7 +145,7 @@ def test_shards_sum_to_the_unsharded_frame(oracle, shards, tile):
     acc = np.zeros_like(full)
     owned = np.zeros(full.shape[:2], np.int32)
     for s in range(shards):
-        part = sc.render(100, 60, 4, shard_index=s, shard_count=shards, tile=tile)
+        part = sc.render(100, 60, 4, shard_index=s, shard_count=shards, tile=tile, schedule=1 + (s & 1))
         part_o = oracle.render(d, 100, 60, 4, shard_index=s, shard_count=shards, tile=tile)
         assert_bit_exact(part, part_o, "shard %d/%d" % (s, shards))
         owned += (part.sum(axis=2) != 0)
@@ -157,9 +163,10 @@ def test_full_size_frame_properties(oracle):
     a = sc.render(1024, 1024, 16)
     b = sc.render(1024, 1024, 16)
     assert_bit_exact(a, b, "determinism")
+    assert_bit_exact(sc.render(1024, 1024, 16, schedule=abi.SCHEDULE_REFILL), a, "persistent lanes")
     acc = np.zeros_like(a)
     for s in range(8):
-        acc += sc.render(1024, 1024, 16, shard_index=s, shard_count=8)
+        acc += sc.render(1024, 1024, 16, shard_index=s, shard_count=8, schedule=1 + (s & 1))
     assert_bit_exact(acc, a, "8 shards")
     st = sc.stats()
     assert st.paths == 1024 * 1024 * 16 // 8 and st.kernel_ms > 0
@@ -192,7 +199,7 @@ def test_render_into_device_memory_and_single_rank_rccl(oracle):
 def test_bad_render_arguments_are_errors():
     sc = pt.Scene(pt.builtin_scene("cornell", 1.0))
     for kw in (dict(nx=0, ny=8, ns=1), dict(nx=8, ny=8, ns=0), dict(nx=8, ny=8, ns=1, shard_index=2, shard_count=2),
-               dict(nx=8, ny=8, ns=1, max_depth=-1), dict(nx=8, ny=8, ns=1, pipeline=99)):
+               dict(nx=8, ny=8, ns=1, max_depth=-1), dict(nx=8, ny=8, ns=1, pipeline=99), dict(nx=8, ny=8, ns=1, schedule=7)):
         with pytest.raises(pt.PtError) as e:
             sc.render(**kw)
         assert e.value.code == abi.ERR_INVALID
