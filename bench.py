@@ -23,10 +23,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Algorithmic work of one Cornell path under the reference's arithmetic (one FLOP = one fp32
-# add/sub/mul/compare/min/max/div/sqrt, no FMA credit because parity forbids contraction):
-# 52.4 rectangle tests, 2.81 closest-hit searches and 1.81 diffuse scatters per path.
-FLOP_PER_PATH = {"cornell": 1200.0}
+# Algorithmic work of one path under the reference's arithmetic (one FLOP = one fp32
+# add/sub/mul/compare/min/max/div/sqrt, no FMA credit because parity forbids contraction), counted
+# by the instrumented build of the CPU checker: bench/work_model.py -> bench/work_model.json.
+# Cornell: 52.4 rectangle tests, 2.81 closest-hit searches, 1.81 diffuse scatters, 799 FLOP per path.
+with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
+    FLOP_PER_PATH = {k: v["flop_per_path"] for k, v in json.load(_f)["configs"].items()}
+# HBM bytes one launch moves, from the committed rocprofv3 PMC pass (FETCH_SIZE + WRITE_SIZE with
+# the guide's unit and gfx950 corrections): the frame is written once, the scene stays in cache.
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "pmc_cornell1024x512_k_render_fused.json")
 # fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).
 PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
@@ -40,7 +45,7 @@ def main():
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--depth", type=int, default=25)
     ap.add_argument("--scene", default="cornell")
-    ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the CPU baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=512, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -136,10 +141,17 @@ def main():
         roofline = None
         if flop is not None:
             achieved = shard_paths * flop / (k_ms * 1e-3) / 1e12
+            traffic = None
+            if args.scene == "cornell" and nx == 1024 and ny == 1024 and world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
+                with open(PMC_TRAFFIC_FILE) as f:
+                    d = json.load(f)["_derived"]
+                traffic = d["fetch_bytes_per_launch_corrected_x2"] + d["write_kib_per_launch"] * 1024.0
             roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None,
-                        "kernel": "k_render_fused", "kernel_ms": k_ms, "flop_per_path": flop,
-                        "paths_per_launch": shard_paths}
+                        "frac": achieved / PEAK_VALU_TFLOPS, "traffic": traffic,
+                        "kernel": "k_render_refill" if scene.stats().schedule == 2 else "k_render_tiles",
+                        "kernel_ms": k_ms, "flop_per_path": flop, "paths_per_launch": shard_paths,
+                        "peak_note": "fp32 VALU with packed issue, no FMA credit (parity forbids contraction); "
+                                     "%.1f TFLOP/s un-packed" % (PEAK_VALU_TFLOPS / 2)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from tests import _oracle

@@ -502,6 +502,7 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
+        sc->last.schedule = ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
     }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;

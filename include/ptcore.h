@@ -194,7 +194,9 @@ typedef struct PtRenderStats {
     int32_t  n_launches;     /* kernel launches in the call                               */
     int32_t  pipeline;       /* scheduler that ran                                        */
     uint64_t paths;          /* camera samples traced by this call (this shard only)      */
-    uint64_t reserved[4];
+    int32_t  schedule;       /* PtSchedule the fused pipeline ran (TILES or REFILL), else 0 */
+    int32_t  reserved0;
+    uint64_t reserved[3];
 } PtRenderStats;
 
 typedef struct PtScene PtScene;

@@ -34,6 +34,31 @@
 /* include/ptRNG.h and friends use CUDART_PI_F from CUDA's math_constants.h */
 #define PI_F 3.141592654f
 
+/* ---- work model -------------------------------------------------------------
+ * Built with -DPT_ORACLE_COUNT (liboracle_count.so) every function adds the arithmetic it
+ * performs to per-thread counters, so that one render yields the algorithmic work of the
+ * reference's own evaluation: FL = fp32 add/sub/mul/compare/min/max/div/sqrt (one each, no
+ * FMA credit), TR = libm calls (sin, cos, log, pow, atan2, asin), IO = integer operations of
+ * the generators and the noise lattice, plus event counts.  The plain build compiles them out. */
+#ifdef PT_ORACLE_COUNT
+typedef struct {
+    uint64_t flop, libm, iop, draws, paths, world_hits, rect_tests, sphere_tests, triangle_tests,
+             aabb_tests, diffuse_scatters, accepted_hits;
+} work_t;
+#define WORK_FIELDS 12
+static __thread work_t W;
+static work_t W_total;
+#define FL(n) (W.flop += (n))
+#define TR(n) (W.libm += (n))
+#define IO(n) (W.iop += (n))
+#define EV(field) (W.field += 1)
+#else
+#define FL(n) ((void)0)
+#define TR(n) ((void)0)
+#define IO(n) ((void)0)
+#define EV(field) ((void)0)
+#endif
+
 typedef struct { float x, y, z; } v3;
 typedef struct { v3 o, d; float time; } ray_t;
 typedef struct { uint64_t state, inc; } pcg_t;
@@ -45,38 +70,43 @@ typedef struct {
 
 /* ---- Vector3 (include/ptVector3.h) --------------------------------------- */
 static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
-static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }          /* :136 */
-static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }          /* :142 */
-static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }          /* :148 */
-static inline v3 smul(float s, v3 a) { return V(s * a.x, s * a.y, s * a.z); }             /* :160 */
-static inline v3 vmuls(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }            /* :172 */
-static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }            /* :166 true divides */
+static inline v3 vadd(v3 a, v3 b) { FL(3); return V(a.x + b.x, a.y + b.y, a.z + b.z); }          /* :136 */
+static inline v3 vsub(v3 a, v3 b) { FL(3); return V(a.x - b.x, a.y - b.y, a.z - b.z); }          /* :142 */
+static inline v3 vmul(v3 a, v3 b) { FL(3); return V(a.x * b.x, a.y * b.y, a.z * b.z); }          /* :148 */
+static inline v3 smul(float s, v3 a) { FL(3); return V(s * a.x, s * a.y, s * a.z); }             /* :160 */
+static inline v3 vmuls(v3 a, float s) { FL(3); return V(a.x * s, a.y * s, a.z * s); }            /* :172 */
+static inline v3 vdivs(v3 a, float s) { FL(3); return V(a.x / s, a.y / s, a.z / s); }            /* :166 true divides */
 static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }                               /* :43 */
-static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }        /* :178 */
-static inline float vsqlen(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }            /* :103 */
-static inline float vlen(v3 a) { return sqrtf(vsqlen(a)); }                               /* :98 */
+static inline float vdot(v3 a, v3 b) { FL(5); return a.x * b.x + a.y * b.y + a.z * b.z; }        /* :178 */
+static inline float vsqlen(v3 a) { FL(5); return a.x * a.x + a.y * a.y + a.z * a.z; }            /* :103 */
+static inline float vlen(v3 a) { FL(1); return sqrtf(vsqlen(a)); }                               /* :98 */
 static inline v3 vcross(v3 a, v3 b)                                                       /* :184 */
 {
+    FL(9);
     return V(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
 }
 static inline v3 vunit(v3 a) { return vdivs(a, vlen(a)); }                                /* :192 */
 static inline v3 vdiv_eq(v3 a, float s)                                                   /* :89 operator/= */
 {
     const float inv = 1 / s;
+    FL(4);
     return V(a.x * inv, a.y * inv, a.z * inv);
 }
 static inline v3 vmake_unit(v3 a)                                                         /* :108 */
 {
     float k = 1 / vlen(a);
+    FL(4);
     return V(a.x * k, a.y * k, a.z * k);
 }
-static inline v3 vreflect(v3 v, v3 n) { return vsub(v, smul(2 * vdot(v, n), n)); }        /* :198 */
+static inline v3 vreflect(v3 v, v3 n) { FL(1); return vsub(v, smul(2 * vdot(v, n), n)); }        /* :198 */
 static int vrefract(v3 v, v3 n, float ni_over_nt, v3* refracted)                          /* :204 */
 {
     v3 uv = vunit(v);
     float dt = vdot(uv, n);
     float disc = 1 - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    FL(6);
     if (disc > 0) {
+        FL(1);
         *refracted = vsub(smul(ni_over_nt, vsub(uv, vmuls(n, dt))), vmuls(n, sqrtf(disc)));
         return 1;
     }
@@ -87,6 +117,7 @@ static inline v3 ray_at(const ray_t* r, float t) { return vadd(r->o, smul(t, r->
 /* ---- RNG (include/ptRNG.h) ------------------------------------------------ */
 static uint32_t pcg_u32(pcg_t* g)                                                         /* :122-131 */
 {
+    IO(11);
     uint64_t old = g->state;
     g->state = old * 0x5851f42d4c957f2dULL + g->inc;
     uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
@@ -103,6 +134,7 @@ static void pcg_seed(pcg_t* g, uint64_t seed)                                   
 }
 static float pcg_rand(pcg_t* g)                                                           /* :110-113 */
 {
+    FL(2); EV(draws);
     return fminf(0.99999994f, (float)pcg_u32(g) * 2.3283064365386963e-10f);
 }
 static float simple_rng_rand(unsigned* s0, unsigned* s1)                                  /* :38-54 */
@@ -120,12 +152,14 @@ static v3 random_in_unit_sphere(pcg_t* g)                                       
     const float phi = pcg_rand(g) * 2 * PI_F;
     const float z = 1 - 2 * pcg_rand(g);
     const float r = sqrtf(fmaxf(0, 1 - z * z));
+    FL(10); TR(2);
     return V(r * cosf(phi), r * sinf(phi), z);
 }
 static v3 random_in_unit_disk(pcg_t* g)                                                   /* :145-150 */
 {
     const float r = sqrtf(pcg_rand(g));
     const float theta = pcg_rand(g) * 2 * PI_F;
+    FL(5); TR(2);
     return V(r * cosf(theta), r * sinf(theta), 0);
 }
 static v3 random_cosine_direction(pcg_t* g)                                               /* :152-161 */
@@ -136,6 +170,7 @@ static v3 random_cosine_direction(pcg_t* g)                                     
     float phi = 2 * PI_F * r1;
     float x = cosf(phi) * 2 * sqrtf(r2);   /* the factor 2 is the reference's */
     float y = sinf(phi) * 2 * sqrtf(r2);
+    FL(10); TR(2);
     return V(x, y, z);
 }
 static v3 random_to_unit_sphere(float radius, float dist_sqrd, pcg_t* g)                  /* :163-172 */
@@ -146,6 +181,7 @@ static v3 random_to_unit_sphere(float radius, float dist_sqrd, pcg_t* g)        
     float phi = 2 * PI_F * r1;
     float x = cosf(phi) * sqrtf(1 - z * z);
     float y = sinf(phi) * sqrtf(1 - z * z);
+    FL(17); TR(2);
     return V(x, y, z);
 }
 
@@ -155,6 +191,7 @@ static void onb_from_w(onb_t* b, v3 n)
 {
     b->w = vunit(n);
     v3 a;
+    FL(1);
     if (fabsf(b->w.x) > 0.9f) a = V(0, 1, 0); else a = V(1, 0, 0);
     b->v = vunit(vcross(b->w, a));
     b->u = vcross(b->w, b->v);
@@ -180,10 +217,11 @@ static const unsigned char PERM[256] = {
 };
 static inline int perm(int i) { return PERM[i & 255]; }   /* table is periodic with period 256 */
 
-static inline float fade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }         /* :19-23 */
-static inline float lerp(float t, float a, float b) { return a + t * (b - a); }           /* :25-29 */
+static inline float fade(float t) { FL(7); return t * t * t * (t * (t * 6 - 15) + 10); }         /* :19-23 */
+static inline float lerp(float t, float a, float b) { FL(3); return a + t * (b - a); }           /* :25-29 */
 static inline float grad(int hash, float x, float y, float z)                             /* :31-38 */
 {
+    FL(1); IO(8);
     int h = hash & 15;
     float u = ((h < 8) || (h == 12) || (h == 13)) ? x : y;
     float v = ((h < 4) || (h == 12) || (h == 13)) ? y : z;
@@ -191,6 +229,7 @@ static inline float grad(int hash, float x, float y, float z)                   
 }
 static float noise3(v3 p)                                                                 /* :114-140 */
 {
+    FL(18); IO(30);          /* 3 floors, 3 fractions, 12 lattice offsets */
     int xi = (int)floorf(p.x) & 255;
     int yi = (int)floorf(p.y) & 255;
     int zi = (int)floorf(p.z) & 255;
@@ -215,6 +254,7 @@ static float turbulence(v3 p, int depth)                                        
     v3 tp = p;
     float weight = 1;
     for (int i = 0; i < depth; i++) {
+        FL(3);
         accum += weight * noise3(tp);
         weight *= 0.5f;
         tp = vmuls(tp, 2.0f);
@@ -230,15 +270,18 @@ static v3 texture_value(const PtSceneDesc* sc, int tex, float u, float v, v3 p)
     case PT_TEX_CONSTANT:                                                                 /* :47-50 */
         return V(t->color[0], t->color[1], t->color[2]);
     case PT_TEX_CHECKER: {                                                                /* :90-97 */
+        FL(6); TR(3);
         float sines = sinf(t->scale * p.x) * sinf(t->scale * p.y) * sinf(t->scale * p.z);
         if (sines < 0) return texture_value(sc, t->odd, u, v, p);
         return texture_value(sc, t->even, u, v, p);
     }
     case PT_TEX_NOISE: {                                                                  /* :142-146 */
+        FL(5); TR(1);
         float n = 0.5f * (1 + sinf(t->scale * p.z + 10 * turbulence(p, 7)));
         return V(n, n, n);
     }
     case PT_TEX_IMAGE: {                                                                  /* :187-199 */
+        FL(7); IO(10);
         int nx = t->nx, ny = t->ny;
         int i = (int)(u * nx);
         int j = (int)((1 - v) * ny - 0.001f);
@@ -260,6 +303,7 @@ static v3 texture_value(const PtSceneDesc* sc, int tex, float u, float v, v3 p)
 
 static void get_uv(v3 p, float* u, float* v)                                              /* ptSphere.h:22-28 */
 {
+    FL(5); TR(2);
     float phi = atan2f(p.z, p.x);
     float theta = asinf(p.y);
     *u = 1 - (phi + PI_F) / (2 * PI_F);
@@ -275,8 +319,10 @@ static int sphere_hit(const float* q, int mat, const ray_t* r, float tmin, float
     float b = vdot(oc, r->d);
     float c = vdot(oc, oc) - radius * radius;
     float disc = b * b - a * c;
+    FL(6); EV(sphere_tests);
     if (disc > 0) {
         float temp = (-b - sqrtf(disc)) / a;
+        FL(5);
         if (temp < tmax && temp > tmin) {
             rec->t = temp;
             rec->p = ray_at(r, rec->t);
@@ -285,6 +331,7 @@ static int sphere_hit(const float* q, int mat, const ray_t* r, float tmin, float
             return 1;                     /* rec->u, rec->v are NOT written (stale), as in the reference */
         }
         temp = (-b + sqrtf(disc)) / a;
+        FL(5);
         if (temp < tmax && temp > tmin) {
             rec->t = temp;
             rec->p = ray_at(r, rec->t);
@@ -300,6 +347,7 @@ static v3 msphere_center(const float* q, float time)                            
 {
     v3 c0 = V(q[0], q[1], q[2]), c1 = V(q[3], q[4], q[5]);
     float t0 = q[6], t1 = q[7];
+    FL(3);
     return vadd(c0, smul((time - t0) / (t1 - t0), vsub(c1, c0)));
 }
 static int msphere_hit(const float* q, int mat, const ray_t* r, float tmin, float tmax, hitrec* rec)
@@ -310,8 +358,10 @@ static int msphere_hit(const float* q, int mat, const ray_t* r, float tmin, floa
     float b = vdot(oc, r->d);
     float c = vdot(oc, oc) - radius * radius;
     float disc = b * b - a * c;
+    FL(6); EV(sphere_tests);
     if (disc > 0) {
         float temp = (-b - sqrtf(disc)) / a;
+        FL(5);
         if (temp < tmax && temp > tmin) {
             rec->t = temp;
             rec->p = ray_at(r, rec->t);
@@ -321,6 +371,7 @@ static int msphere_hit(const float* q, int mat, const ray_t* r, float tmin, floa
             return 1;
         }
         temp = (-b + sqrtf(disc)) / a;
+        FL(5);
         if (temp < tmax && temp > tmin) {
             rec->t = temp;
             rec->p = ray_at(r, rec->t);
@@ -343,10 +394,13 @@ static int rect_hit(int kaxis, float a0, float a1, float b0, float b1, float k, 
     else if (kaxis == 1) { ok = r->o.y; dk = r->d.y; oa = r->o.x; da = r->d.x; ob = r->o.z; db = r->d.z; }
     else                 { ok = r->o.x; dk = r->d.x; oa = r->o.y; da = r->d.y; ob = r->o.z; db = r->d.z; }
     float t = (k - ok) / dk;
+    FL(4); EV(rect_tests);
     if (t < t0 || t > t1) return 0;
     float a = oa + t * da;
     float b = ob + t * db;
+    FL(8);
     if (a < a0 || a > a1 || b < b0 || b > b1) return 0;
+    FL(6);
     rec->u = (a - a0) / (a1 - a0);
     rec->v = (b - b0) / (b1 - b0);
     rec->t = t;
@@ -393,15 +447,20 @@ static int triangle_hit(const PtSceneDesc* sc, const PtShape* s, const ray_t* r,
     v3 edge2 = vsub(v2, v0);
     v3 pvec = vcross(r->d, edge2);
     float det = vdot(edge1, pvec);
+    FL(1); EV(triangle_tests);
     if (det < 0.0001f) return 0;
     v3 tvec = vsub(r->o, v0);
     float u = vdot(tvec, pvec);
+    FL(2);
     if (u < 0 || u > det) return 0;
     v3 qvec = vcross(tvec, edge1);
     float v = vdot(r->d, qvec);
+    FL(3);
     if (v < 0 || u + v > det) return 0;
     float t = vdot(edge2, qvec);             /* NOT divided by det, as in the reference */
+    FL(2);
     if (t < t_min || t > t_max) return 0;
+    FL(17);
     const float inv_det = 1 / det;
     u *= inv_det;
     v *= inv_det;
@@ -477,12 +536,14 @@ static int xformed_hit(const PtSceneDesc* sc, const PtXform* xf, int nxf, int k,
     } else {
         const float sinT = x->v[0], cosT = x->v[1];
         ray_t rot = *r;
+        FL(12);
         rot.o.x = cosT * r->o.x - sinT * r->o.z;
         rot.o.z = sinT * r->o.x + cosT * r->o.z;
         rot.d.x = cosT * r->d.x - sinT * r->d.z;
         rot.d.z = sinT * r->d.x + cosT * r->d.z;
         if (xformed_hit(sc, xf, nxf, k + 1, s, bvh, &rot, tmin, tmax, rec, rng)) {
             v3 p = rec->p, n = rec->n;
+            FL(12);
             p.x = cosT * rec->p.x + sinT * rec->p.z;
             p.z = -sinT * rec->p.x + cosT * rec->p.z;
             n.x = cosT * rec->n.x + sinT * rec->n.z;
@@ -499,7 +560,9 @@ static int xformed_hit(const PtSceneDesc* sc, const PtXform* xf, int nxf, int k,
 static int aabb_hit(const float* bmin, const float* bmax, const ray_t* r, float tmin, float tmax)
 {
     const float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
+    EV(aabb_tests);
     for (int a = 0; a < 3; a++) {
+        FL(9);
         const float invD = 1 / d[a];
         float t0 = (bmin[a] - o[a]) * invD;
         float t1 = (bmax[a] - o[a]) * invD;
@@ -545,14 +608,18 @@ static int medium_hit(const PtSceneDesc* sc, int m, const ray_t* r, float t0, fl
     memset(&rec1, 0, sizeof rec1);
     memset(&rec2, 0, sizeof rec2);
     if (shape_hit(sc, med->boundary, r, -FLT_MAX, FLT_MAX, &rec1, rng)) {
+        FL(1);
         if (shape_hit(sc, med->boundary, r, (float)((double)rec1.t + 0.0001), FLT_MAX, &rec2, rng)) {
+            FL(4);
             if (rec1.t < t0) rec1.t = t0;
             if (rec2.t > t1) rec2.t = t1;
             if (rec1.t > rec2.t) return 0;
             if (rec1.t < 0) rec1.t = 0;
             float dist_inside = (rec2.t - rec1.t) * vlen(r->d);
             float hit_dist = -(1 / med->density) * logf(pcg_rand(rng));
+            FL(5); TR(1);
             if (hit_dist < dist_inside) {
+                FL(2);
                 rec->t = rec1.t + hit_dist / vlen(r->d);
                 rec->p = ray_at(r, rec->t);
                 rec->n = V(1, 0, 0);
@@ -570,6 +637,7 @@ static int world_hit(const PtSceneDesc* sc, const ray_t* r, float tmin, float tm
                      hitrec* rec, pcg_t* rng)
 {
     hitrec temp;
+    EV(world_hits);
     memset(&temp, 0, sizeof temp);     /* the reference leaves temp_rec uninitialised */
     int hit_anything = 0;
     float closest = tmax;
@@ -584,6 +652,7 @@ static int world_hit(const PtSceneDesc* sc, const ray_t* r, float tmin, float tm
                             r, tmin, closest, &temp, rng);
         }
         if (h) {
+            EV(accepted_hits);
             hit_anything = 1;
             closest = temp.t;
             *rec = temp;
@@ -602,6 +671,7 @@ static float light_shape_pdf(const PtSceneDesc* sc, int shape, v3 o, v3 v, pcg_t
     memset(&rec, 0, sizeof rec);
     if (s->xform_count == 0 && s->type == PT_SHAPE_RECT_XZ) {                             /* ptRectangle.h:77-89 */
         if (rect_hit(1, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], s->material, &r, 0.001f, FLT_MAX, &rec)) {
+            FL(8);
             float area = (s->p[1] - s->p[0]) * (s->p[3] - s->p[2]);
             float dist_sqrd = rec.t * rec.t * vsqlen(v);
             float cosine = fabsf(vdot(v, rec.n) / vlen(v));
@@ -613,6 +683,7 @@ static float light_shape_pdf(const PtSceneDesc* sc, int shape, v3 o, v3 v, pcg_t
         if (sphere_hit(s->p, s->material, &r, 0.001f, FLT_MAX, &rec)) {
             v3 center = V(s->p[0], s->p[1], s->p[2]);
             float radius = s->p[3];
+            FL(8);
             float cos_theta_max = sqrtf(1 - radius * radius / vsqlen(vsub(center, o)));
             float solid_angle = 2 * PI_F * (1 - cos_theta_max);
             return 1 / solid_angle;
@@ -629,6 +700,7 @@ static v3 light_shape_random(const PtSceneDesc* sc, int shape, v3 o, pcg_t* rng)
         /* g++ evaluates the constructor arguments right to left: z is drawn before x */
         float rz = pcg_rand(rng);
         float rx = pcg_rand(rng);
+        FL(6);
         v3 rp = V(s->p[0] + rx * (s->p[1] - s->p[0]), s->p[4], s->p[2] + rz * (s->p[3] - s->p[2]));
         return vsub(rp, o);
     }
@@ -645,6 +717,7 @@ static v3 light_shape_random(const PtSceneDesc* sc, int shape, v3 o, pcg_t* rng)
 static float lights_pdf(const PtSceneDesc* sc, v3 o, v3 v, pcg_t* rng)
 {
     if (!sc->lights_is_list) return light_shape_pdf(sc, sc->lights[0], o, v, rng);
+    FL(1 + 2 * sc->n_lights);
     float weight = 1 / (float)sc->n_lights;                                               /* ptHitableList.h:29-38 */
     float sum = 0;
     for (int i = 0; i < sc->n_lights; i++) sum += weight * light_shape_pdf(sc, sc->lights[i], o, v, rng);
@@ -653,6 +726,7 @@ static float lights_pdf(const PtSceneDesc* sc, v3 o, v3 v, pcg_t* rng)
 static v3 lights_random(const PtSceneDesc* sc, v3 o, pcg_t* rng)
 {
     if (!sc->lights_is_list) return light_shape_random(sc, sc->lights[0], o, rng);
+    FL(1);
     int index = (int)(pcg_rand(rng) * sc->n_lights);                                      /* ptHitableList.h:40-44 */
     return light_shape_random(sc, sc->lights[index], o, rng);
 }
@@ -661,6 +735,7 @@ static v3 lights_random(const PtSceneDesc* sc, v3 o, pcg_t* rng)
 
 static float schlick(float cs, float ri)                                                  /* :31-37 */
 {
+    FL(8); TR(1);
     float r0 = (1 - ri) / (1 + ri);
     r0 = r0 * r0;
     return r0 + (1 - r0) * powf(1 - cs, 5);
@@ -672,6 +747,7 @@ static v3 material_emitted(const PtSceneDesc* sc, int mat, const ray_t* r_in, co
 {
     const PtMaterial* m = &sc->materials[mat];
     if (m->type == PT_MAT_DIFFUSE_LIGHT) {                                                /* :266-272 */
+        FL(1);
         if (vdot(rec->n, r_in->d) < 0) return texture_value(sc, m->texture, rec->u, rec->v, rec->p);
         return V(0, 0, 0);
     }
@@ -700,6 +776,7 @@ static int material_scatter(const PtSceneDesc* sc, int mat, const ray_t* r_in, c
     }
     case PT_MAT_DIELECTRIC: {                                                             /* :184-224 */
         const float ref_idx = m->param;
+        FL(5);
         srec->is_specular = 1;
         srec->cosine_pdf = 0;
         srec->attenuation = V(1, 1, 1);
@@ -740,6 +817,7 @@ static float material_scattering_pdf(const PtSceneDesc* sc, int mat, const hitre
     const PtMaterial* m = &sc->materials[mat];
     if (m->type == PT_MAT_LAMBERTIAN) {                                                   /* :80-85 */
         float cosine = vdot(rec->n, vunit(scattered->d));
+        FL(2);
         if (cosine < 0) return 0;
         return cosine / PI_F;
     }
@@ -751,6 +829,7 @@ static float material_scattering_pdf(const PtSceneDesc* sc, int mat, const hitre
 static float cosine_pdf_value(const onb_t* uvw, v3 dir)                                   /* :46-53 */
 {
     float cosine = vdot(vunit(dir), uvw->w);
+    FL(2);
     if (cosine > 0) return cosine / PI_F;
     return 0;
 }
@@ -760,6 +839,7 @@ static v3 ambient_emitted(const PtSceneDesc* sc, const ray_t* r)
 {
     if (sc->ambient_type == PT_AMBIENT_SKY) {                                             /* :86-91 */
         v3 unit_dir = vunit(r->d);
+        FL(3);
         float t = 0.5f * (unit_dir.y + 1);
         return vadd(smul(1 - t, V(1, 1, 1)), smul(t, V(0.5f, 0.7f, 1.0f)));
     }
@@ -775,6 +855,7 @@ static ray_t camera_get_ray(const PtSceneDesc* sc, float s, float t, pcg_t* rng)
     float time0 = c[21], time1 = c[22], lens_radius = c[23];
     v3 rd = smul(lens_radius, random_in_unit_disk(rng));
     v3 offset = vadd(vmuls(cu, rd.x), vmuls(cv, rd.y));
+    FL(3);
     float time = time0 + pcg_rand(rng) * (time1 - time0);
     ray_t r;
     r.o = vadd(origin, offset);
@@ -787,6 +868,7 @@ static ray_t camera_get_ray(const PtSceneDesc* sc, float s, float t, pcg_t* rng)
 
 static v3 de_nan(v3 c)                                                                    /* :46-53 */
 {
+    FL(3);
     if (!(c.x == c.x)) c.x = 0;
     if (!(c.y == c.y)) c.y = 0;
     if (!(c.z == c.z)) c.z = 0;
@@ -808,11 +890,13 @@ static v3 color(const PtSceneDesc* sc, ray_t current, pcg_t* rng, int max_depth)
                     current = srec.specular_ray;
                 } else {
                     onb_t uvw;
+                    EV(diffuse_scatters);
                     onb_from_w(&uvw, rec.n);                                              /* CosinePdf pdf(rec.normal) */
                     ray_t scattered;
                     float pdf_value;
                     if (sc->n_lights > 0) {
                         v3 dir;                                                           /* MixturePdf::generate, ptPDF.h:94-100 */
+                        FL(4);
                         if (pcg_rand(rng) < 0.5f) dir = lights_random(sc, rec.p, rng);
                         else dir = onb_local(&uvw, random_cosine_direction(rng));
                         scattered.o = rec.p; scattered.d = dir; scattered.time = current.time;
@@ -843,12 +927,14 @@ static v3 render_pixel(const PtSceneDesc* sc, int x, int y, int nx, int ny, int 
 {                                                                                         /* :153-169 */
     v3 accum = V(0, 0, 0);
     for (int s = 0; s < ns; s++) {
+        FL(4); EV(paths);
         float u = (x + pcg_rand(rng)) / (float)nx;
         float v = (y + pcg_rand(rng)) / (float)ny;
         ray_t r = camera_get_ray(sc, u, v, rng);
         accum = vadd(accum, de_nan(color(sc, r, rng, max_depth)));
     }
     accum = vdiv_eq(accum, (float)ns);
+    FL(6);
     accum.x = sqrtf(fmaxf(0.0f, accum.x));
     accum.y = sqrtf(fmaxf(0.0f, accum.y));
     accum.z = sqrtf(fmaxf(0.0f, accum.z));
@@ -871,24 +957,55 @@ int oracle_render(const PtSceneDesc* sc, const PtRenderParams* p, float* out_rgb
 {
     const int nx = p->nx, ny = p->ny;
     (void)n_threads;
-#ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+#ifdef PT_ORACLE_COUNT
+    memset(&W_total, 0, sizeof W_total);
 #endif
-    for (int y = 0; y < ny; y++) {
-        for (int x = 0; x < nx; x++) {
-            unsigned i = (unsigned)((ny - y - 1) * nx + x);
-            if (!owns_pixel(p, x, ny - y - 1)) {
-                out_rgb[3 * i] = out_rgb[3 * i + 1] = out_rgb[3 * i + 2] = 0.0f;
-                continue;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    {
+#ifdef PT_ORACLE_COUNT
+        memset(&W, 0, sizeof W);
+#endif
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int y = 0; y < ny; y++) {
+            for (int x = 0; x < nx; x++) {
+                unsigned i = (unsigned)((ny - y - 1) * nx + x);
+                if (!owns_pixel(p, x, ny - y - 1)) {
+                    out_rgb[3 * i] = out_rgb[3 * i + 1] = out_rgb[3 * i + 2] = 0.0f;
+                    continue;
+                }
+                pcg_t rng;
+                pcg_seed(&rng, i);
+                v3 c = render_pixel(sc, x, y, nx, ny, p->ns, &rng, p->max_depth);
+                out_rgb[3 * i] = c.x; out_rgb[3 * i + 1] = c.y; out_rgb[3 * i + 2] = c.z;
             }
-            pcg_t rng;
-            pcg_seed(&rng, i);
-            v3 c = render_pixel(sc, x, y, nx, ny, p->ns, &rng, p->max_depth);
-            out_rgb[3 * i] = c.x; out_rgb[3 * i + 1] = c.y; out_rgb[3 * i + 2] = c.z;
         }
+#ifdef PT_ORACLE_COUNT
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            const uint64_t* src = (const uint64_t*)&W;
+            uint64_t* dst = (uint64_t*)&W_total;
+            for (int k = 0; k < WORK_FIELDS; k++) dst[k] += src[k];
+        }
+#endif
     }
     return 0;
 }
+
+#ifdef PT_ORACLE_COUNT
+/* Counters of the most recent oracle_render, in the field order of work_t. */
+int oracle_work_counters(uint64_t* out, int n)
+{
+    const uint64_t* src = (const uint64_t*)&W_total;
+    for (int k = 0; k < n && k < WORK_FIELDS; k++) out[k] = src[k];
+    return WORK_FIELDS;
+}
+#endif
 
 int oracle_trace_closest(const PtSceneDesc* sc, const PtRay* rays, size_t n, int32_t* prim_id, float* t)
 {

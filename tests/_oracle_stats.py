@@ -1,8 +1,8 @@
-"""Instrumented build of the oracle: counts closest-hit searches, RNG draws and diffuse scatters."""
+"""Counting build of the oracle (oracle/liboracle_count.so, -DPT_ORACLE_COUNT): closest-hit
+searches, RNG draws, diffuse scatters and arithmetic per path.  Test infrastructure only."""
 import ctypes as C
 import os
 import subprocess
-import tempfile
 
 import numpy as np
 
@@ -10,44 +10,39 @@ import gpupathtracer_amd as pt
 from gpupathtracer_amd import _abi as A
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ["flop", "libm", "iop", "draws", "paths", "world_hits", "rect_tests", "sphere_tests", "triangle_tests",
+          "aabb_tests", "diffuse_scatters", "accepted_hits"]
 _LIB = None
 
 
-def _build():
-    src = open(os.path.join(ROOT, "oracle", "pt_oracle.c")).read()
-    reps = [
-        ("static float pcg_rand(pcg_t* g)", "long g_draws = 0, g_whits = 0, g_diffuse = 0;\nstatic float pcg_rand(pcg_t* g)"),
-        ("    return fminf(0.99999994f, (float)pcg_u32(g) * 2.3283064365386963e-10f);",
-         "    __sync_fetch_and_add(&g_draws, 1);\n    return fminf(0.99999994f, (float)pcg_u32(g) * 2.3283064365386963e-10f);"),
-        ("    hitrec temp;\n    memset(&temp, 0, sizeof temp);     /* the reference",
-         "    __sync_fetch_and_add(&g_whits, 1);\n    hitrec temp;\n    memset(&temp, 0, sizeof temp);     /* the reference"),
-        ("                    onb_from_w(&uvw, rec.n);                                              /* CosinePdf",
-         "                    __sync_fetch_and_add(&g_diffuse, 1);\n                    onb_from_w(&uvw, rec.n); /* CosinePdf"),
-    ]
-    for a, b in reps:
-        assert a in src, a
-        src = src.replace(a, b, 1)
-    src = src.replace('"../include/ptcore.h"', '"%s"' % os.path.join(ROOT, "include", "ptcore.h"))
-    d = tempfile.mkdtemp(prefix="pt_oracle_stats_")
-    cfile, so = os.path.join(d, "o.c"), os.path.join(d, "o.so")
-    open(cfile, "w").write(src)
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fopenmp", "-shared", "-o", so, cfile, "-lm"])
-    return C.CDLL(so)
+def _load():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(ROOT, "oracle", "liboracle_count.so")
+        src = os.path.join(ROOT, "oracle", "pt_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_count.so"])
+        _LIB = C.CDLL(so)
+        _LIB.oracle_render.argtypes = [C.POINTER(A.PtSceneDesc), C.POINTER(A.PtRenderParams), C.c_void_p, C.c_int]
+        _LIB.oracle_work_counters.argtypes = [C.c_void_p, C.c_int]
+    return _LIB
+
+
+def counters(desc, nx, ny, ns, max_depth=25, threads=8):
+    lib = _load()
+    p = A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=0, shard_count=1, tile_w=8, tile_h=8)
+    img = np.zeros((ny, nx, 3), np.float32)
+    lib.oracle_render(desc.ptr, C.byref(p), img.ctypes.data, threads)
+    cnt = (C.c_uint64 * len(FIELDS))()
+    lib.oracle_work_counters(cnt, len(FIELDS))
+    return dict(zip(FIELDS, [int(v) for v in cnt])), img
 
 
 def run(name, aspect, nx, ny, ns):
-    global _LIB
-    if _LIB is None:
-        _LIB = _build()
-    lib = _LIB
-    lib.oracle_render.argtypes = [C.POINTER(A.PtSceneDesc), C.POINTER(A.PtRenderParams), C.c_void_p, C.c_int]
     d = pt.builtin_scene(name, aspect)
-    for k in ("g_draws", "g_whits", "g_diffuse"):
-        C.c_long.in_dll(lib, k).value = 0
-    p = A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=25, shard_index=0, shard_count=1)
-    img = np.zeros(nx * ny * 3, np.float32)
-    lib.oracle_render(d.ptr, C.byref(p), img.ctypes.data, 8)
+    c, _ = counters(d, nx, ny, ns)
     n = float(nx * ny * ns)
-    return {"world_hits_per_path": C.c_long.in_dll(lib, "g_whits").value / n,
-            "rng_draws_per_path": C.c_long.in_dll(lib, "g_draws").value / n,
-            "diffuse_scatters_per_path": C.c_long.in_dll(lib, "g_diffuse").value / n}
+    assert c["paths"] == nx * ny * ns
+    return {"world_hits_per_path": c["world_hits"] / n, "rng_draws_per_path": c["draws"] / n,
+            "diffuse_scatters_per_path": c["diffuse_scatters"] / n, "flop_per_path": c["flop"] / n,
+            "rect_tests_per_path": c["rect_tests"] / n}

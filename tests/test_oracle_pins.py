@@ -85,6 +85,21 @@ def test_work_statistics_agree_with_survey_probe(name, aspect, nx, ny, ns, key):
         assert abs(st["diffuse_scatters_per_path"] - want["diffuse_scatters_per_path"]) < 0.02
 
 
+def test_work_model_file_matches_the_counting_oracle(oracle):
+    """bench/work_model.json (the roofline's FLOP per path) is what the counting build measures, and
+    the counting build renders the same image as the plain one.  The survey's probe counted 52.4
+    rectangle tests per Cornell path."""
+    from tests import _oracle_stats
+    model = json.load(open(os.path.join(os.path.dirname(HERE), "bench", "work_model.json")))["configs"]["cornell"]
+    d = pt.builtin_scene("cornell", 1.0)
+    c, img = _oracle_stats.counters(d, 96, 96, 32)
+    np.testing.assert_array_equal(img.view(np.uint32), oracle.render(d, 96, 96, 32).view(np.uint32))
+    n = 96 * 96 * 32
+    assert abs(c["flop"] / n - model["flop_per_path"]) < 0.02 * model["flop_per_path"]
+    assert abs(c["rect_tests"] / n - 52.4) < 0.5
+    assert abs(model["rect_tests_per_path"] - 52.4) < 0.2
+
+
 def test_oracle_is_deterministic_across_thread_counts(oracle):
     d = pt.builtin_scene("cornell", 1.0)
     a = oracle.render(d, 48, 48, 4, threads=1)
