@@ -12,6 +12,7 @@ AMBIENT_NONE, AMBIENT_CONSTANT, AMBIENT_SKY = 0, 1, 2
 ACCEL_LIST, ACCEL_LBVH = 0, 1
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL = 0, 1, 2
+STREAM_KEEP_AMBIENT_COLOR = 1
 ID_MISS = -1
 ID_MEDIUM_BASE = 0x40000000
 
@@ -104,7 +105,8 @@ assert C.sizeof(PtRenderParams) == 64
 EXPORTS = [
     "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_trace_closest", "pt_render_stats", "pt_scene_lbvh_nodes", "pt_scene_desc_builtin",
-    "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_device_count",
+    "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",
+    "pt_median_filter", "pt_median_filter_device", "pt_device_count",
     "pt_set_device", "pt_device_synchronize", "pt_device_malloc", "pt_device_free", "pt_memcpy_to_host",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_reduce_frame", "pt_comm_destroy", "pt_libm_eval",
 ]

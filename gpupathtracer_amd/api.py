@@ -53,6 +53,10 @@ def library():
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
     lib.pt_scene_desc_free.restype = None
+    lib.pt_median_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.pt_median_filter_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.pt_scene_desc_from_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, P(P(A.PtSceneDesc))]
+    lib.pt_scene_desc_to_stream.argtypes = [P(A.PtSceneDesc), C.c_void_p, C.c_size_t, P(C.c_size_t), P(C.c_size_t)]
     lib.pt_device_count.argtypes = []
     lib.pt_set_device.argtypes = [C.c_int]
     lib.pt_device_synchronize.argtypes = []
@@ -188,6 +192,38 @@ def builtin_scene(name, aspect, earth_rgb=None, accel=None):
     if accel is not None:
         out.contents.accel = int(accel)
     return SceneDesc(out)
+
+
+def median_filter(image, size=3):
+    """medianFilter3x3 / medianFilter2x2 of the reference (src/ptMain.cu:726-788) on the GPU."""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    assert img.ndim == 3 and img.shape[2] == 3
+    out = np.empty_like(img)
+    _check(library().pt_median_filter(img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0], int(size)))
+    return out
+
+
+def scene_from_stream(data, flags=0, accel=None):
+    """A scene serialised by the reference (world, light shapes, camera, ambient light;
+    src/ptMain.cu:560-572) as a description."""
+    lib = library()
+    blob = bytes(data)
+    out = C.POINTER(A.PtSceneDesc)()
+    _check(lib.pt_scene_desc_from_stream(blob, len(blob), int(flags), C.byref(out)))
+    if accel is not None:
+        out.contents.accel = int(accel)
+    return SceneDesc(out)
+
+
+def scene_to_stream(desc):
+    """(bytes, [world, lights, camera, ambient] section sizes) in the reference's stream format."""
+    lib = library()
+    size = C.c_size_t(0)
+    sections = (C.c_size_t * 4)()
+    _check(lib.pt_scene_desc_to_stream(desc.ptr, None, 0, C.byref(size), sections))
+    buf = C.create_string_buffer(size.value)
+    _check(lib.pt_scene_desc_to_stream(desc.ptr, buf, size.value, C.byref(size), sections))
+    return buf.raw[:size.value], [int(v) for v in sections]
 
 
 def trimesh_scene(grid_n, aspect):

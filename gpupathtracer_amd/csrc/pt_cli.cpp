@@ -3,7 +3,8 @@
 // Same flags and defaults as the reference (src/ptMain.cu:502-549): -q/--quick, -c/--cpu,
 // -m/--median, -w/--width, -h/--height (height, not help), -n/--numsamples, -t/--threads,
 // -d/--maxdepth, -s/--stacksize, -f/--file; plus --scene, --gpus, --accel, --pipeline, which the
-// reference lacks (its scene is a source edit at src/ptMain.cu:559).  The reference parses with
+// reference lacks (its scene is a source edit at src/ptMain.cu:559), and --stream-in / --stream-out,
+// which read and write the scene byte stream main() builds for its device (src/ptMain.cu:560-572).  The reference parses with
 // the vendored cxxopts; getopt_long gives the same short/long spellings here.
 #include <getopt.h>
 
@@ -11,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <iterator>
 #include <string>
 #include <vector>
 
@@ -32,7 +35,7 @@ int main(int argc, char** argv)
 {
     bool quick = false, cpu = false, median = false;
     int ns = 100, nx = 128 * 4, ny = 128 * 4, maxDepth = 25, gpus = 1;
-    std::string outFile = "outputImage.ppm", scene = "random", accel = "auto", pipeline = "fused";
+    std::string outFile = "outputImage.ppm", scene = "random", accel = "auto", pipeline = "fused", streamIn, streamOut;
 
     static const option longopts[] = {
         { "quick", no_argument, nullptr, 'q' }, { "cpu", no_argument, nullptr, 'c' }, { "median", no_argument, nullptr, 'm' },
@@ -41,7 +44,8 @@ int main(int argc, char** argv)
         { "maxdepth", required_argument, nullptr, 'd' }, { "stacksize", required_argument, nullptr, 's' },
         { "file", required_argument, nullptr, 'f' }, { "scene", required_argument, nullptr, 1000 },
         { "gpus", required_argument, nullptr, 1001 }, { "accel", required_argument, nullptr, 1002 },
-        { "pipeline", required_argument, nullptr, 1003 }, { nullptr, 0, nullptr, 0 } };
+        { "pipeline", required_argument, nullptr, 1003 }, { "stream-in", required_argument, nullptr, 1004 },
+        { "stream-out", required_argument, nullptr, 1005 }, { nullptr, 0, nullptr, 0 } };
     int c;
     while ((c = getopt_long(argc, argv, "qcmw:h:n:t:d:s:f:", longopts, nullptr)) != -1) {
         switch (c) {
@@ -59,21 +63,37 @@ int main(int argc, char** argv)
         case 1001: gpus = std::atoi(optarg); break;
         case 1002: accel = optarg; break;
         case 1003: pipeline = optarg; break;
+        case 1004: streamIn = optarg; break;
+        case 1005: streamOut = optarg; break;
         default:
             std::cerr << "usage: ptrace [-q] [-w W] [-h H] [-n SPP] [-d DEPTH] [-f out.{ppm,hdr,png,tga,bmp}]\n"
                          "              [--scene simple_spheres|simple_light|random|cornell|cornell_spheres|final|trimesh]\n"
-                         "              [--gpus N] [--accel auto|list|lbvh] [--pipeline fused|wavefront]" << std::endl;
+                         "              [--gpus N] [--accel auto|list|lbvh] [--pipeline fused|wavefront]\n"
+                         "              [--stream-in scene.bin] [--stream-out scene.bin] [-m]" << std::endl;
             return EXIT_FAILURE;
         }
     }
     if (cpu) { std::cerr << "-c/--cpu: this build renders on the GPU only; it has no CPU path." << std::endl; return EXIT_FAILURE; }
-    if (median) std::cerr << "-m/--median: the median post-filter is not part of this build; writing the unfiltered image." << std::endl;
     if (quick) { nx /= 8; ny /= 8; ns /= 16; }   // src/ptMain.cu:544-549
     if (nx <= 0 || ny <= 0 || ns <= 0 || gpus <= 0) { std::cerr << "width, height, numsamples and gpus must be positive" << std::endl; return EXIT_FAILURE; }
 
     const float aspect = float(nx) / float(ny);
     PtSceneDesc* desc = nullptr;
-    if (pt_scene_desc_builtin(scene.c_str(), aspect, nullptr, 0, 0, &desc) != PT_OK) return fail("scene");
+    if (!streamIn.empty()) {                     // a scene the reference serialised (its camera fixes the aspect)
+        std::ifstream f(streamIn, std::ios::binary);
+        if (!f) { std::cerr << "cannot open " << streamIn << std::endl; return EXIT_FAILURE; }
+        const std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        if (pt_scene_desc_from_stream(blob.data(), blob.size(), 0, &desc) != PT_OK) return fail("scene stream");
+    } else if (pt_scene_desc_builtin(scene.c_str(), aspect, nullptr, 0, 0, &desc) != PT_OK) return fail("scene");
+    if (!streamOut.empty()) {
+        size_t size = 0;
+        if (pt_scene_desc_to_stream(desc, nullptr, 0, &size, nullptr) != PT_OK) return fail("scene stream");
+        std::vector<char> blob(size);
+        if (pt_scene_desc_to_stream(desc, blob.data(), blob.size(), &size, nullptr) != PT_OK) return fail("scene stream");
+        std::ofstream f(streamOut, std::ios::binary);
+        f.write(blob.data(), (std::streamsize)blob.size());
+        if (!f) { std::cerr << "cannot write " << streamOut << std::endl; return EXIT_FAILURE; }
+    }
     if (accel == "lbvh") desc->accel = PT_ACCEL_LBVH;
     else if (accel == "list") desc->accel = PT_ACCEL_LIST;
     else if (desc->n_world > 32 && desc->n_media == 0 && desc->n_bvhs == 0) desc->accel = PT_ACCEL_LBVH;
@@ -113,6 +133,12 @@ int main(int argc, char** argv)
     std::cerr << (double)nx * ny * ns / sec / 1e6 << " Mpaths/s (" << sec << " s, " << gpus << " GPU)" << std::endl;
     for (int g = 0; g < gpus; g++) { pt_set_device(g); pt_device_free(frames[(size_t)g]); pt_scene_destroy(scenes[(size_t)g]); }
     pt_scene_desc_free(desc);
+    if (median) {                                // medianFilter3x3 before writeImage, src/ptMain.cu:684-689
+        std::vector<float> filtered(n_floats);
+        pt_set_device(0);
+        if (pt_median_filter(image.data(), filtered.data(), nx, ny, 3) != PT_OK) return fail("median filter");
+        image.swap(filtered);
+    }
 
     std::string err;
     if (!pt::write_image(outFile, image.data(), nx, ny, &err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }

@@ -253,6 +253,38 @@ int  pt_scene_desc_builtin(const char* name, float aspect,
 int  pt_scene_desc_trimesh(int32_t grid_n, float aspect, PtSceneDesc** out_desc);
 void pt_scene_desc_free(PtSceneDesc* desc);
 
+/* The reference's scene byte stream (src/ptStream.cu:56-90) -> description.  Replaces what
+ * allocate_world_kernel does with it on the device: Hitable::Create for the world and for the
+ * light shapes, Camera::Create, AmbientLight::Create, in that order (src/ptMain.cu:423-430).
+ * data/size is the buffer main() filled with world->serialize ... ambientLight->serialize
+ * (src/ptMain.cu:560-572).  Nested lists flatten into the world list, FlipNormals / Translate /
+ * RotateY become the leaf's flag and wrapper chain, a Box record whose child is the constructor's
+ * six rectangles becomes one BOX shape, identical material and texture records are merged.
+ * A ConstantAmbient arrives black, as it does on the reference's device (its deserialize never
+ * reads the colour, include/ptAmbientLight.h:65-73), unless PT_STREAM_KEEP_AMBIENT_COLOR is set.
+ * Errors: PT_ERR_INVALID for a malformed stream, PT_ERR_UNSUPPORTED for a ConstantMedium under
+ * a wrapper.  Free the result with pt_scene_desc_free(). */
+#define PT_STREAM_KEEP_AMBIENT_COLOR 1u
+int  pt_scene_desc_from_stream(const void* data, size_t size, uint32_t flags, PtSceneDesc** out_desc);
+
+/* Description -> the same byte stream, as main()'s serialize sequence writes it
+ * (src/ptMain.cu:560-572): world list, light shapes or null, camera, ambient light or null.
+ * buffer may be NULL to learn the size; *out_size is always the full size;
+ * section_sizes (may be NULL) receives the byte counts of those four sections.
+ * PT_ERR_UNSUPPORTED for a world that holds a BVH: the reference's BVH::serialize writes
+ * nothing (src/ptBVH.cu:97-100). */
+int  pt_scene_desc_to_stream(const PtSceneDesc* desc, void* buffer, size_t capacity, size_t* out_size,
+                             size_t section_sizes[4]);
+
+/* medianFilter3x3 (size 3) / medianFilter2x2 (size 2) of the reference (src/ptMain.cu:726-788),
+ * which its -m flag runs over outImage before writeImage (:684-693): every pixel becomes the
+ * neighbour of rank (count-1)/2 by squared length, edges clamped; equal lengths keep the
+ * neighbourhood's own order, as glibc's stable qsort leaves them.  in and out are nx*ny*3
+ * floats and must not overlap.  The _device form takes device pointers and a hipStream_t. */
+int  pt_median_filter(const float* in_rgb, float* out_rgb, int32_t nx, int32_t ny, int32_t size);
+int  pt_median_filter_device(const void* d_in_rgb, void* d_out_rgb, int32_t nx, int32_t ny, int32_t size,
+                             void* hip_stream);
+
 /* Number of visible HIP devices (0 when there is none); never fails. */
 int  pt_device_count(void);
 

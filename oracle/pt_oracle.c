@@ -1131,6 +1131,35 @@ void oracle_aabb_hits(const float* boxes, const PtRay* rays, int n, float tmin, 
     }
 }
 /* 64-bit FNV-1a over the bytes of a float image. */
+/* medianFilter3x3 / medianFilter2x2 (src/ptMain.cu:700-788): the neighbourhood is sorted with the C
+ * library's qsort under the reference's comparator, exactly as the reference does it. */
+static int median_compare(const void* a, const void* b)                                   /* :700-717 */
+{
+    const v3 v0 = *(const v3*)a, v1 = *(const v3*)b;
+    const float k0 = v0.x * v0.x + v0.y * v0.y + v0.z * v0.z;
+    const float k1 = v1.x * v1.x + v1.y * v1.y + v1.z * v1.z;
+    if (k0 < k1) return -1;
+    if (k0 > k1) return 1;
+    return 0;
+}
+void oracle_median_filter(const float* in, float* out, int nx, int ny, int size)
+{
+    const v3* src = (const v3*)in;
+    v3* dst = (v3*)out;
+    for (int l = 0; l < ny; l++) {
+        const int rows[3] = { l > 0 ? l - 1 : 0, l, l < ny - 1 ? l + 1 : ny - 1 };
+        for (int s = 0; s < nx; s++) {
+            const int cols[3] = { s > 0 ? s - 1 : 0, s, s < nx - 1 ? s + 1 : nx - 1 };
+            v3 hood[9];
+            int n = 0;
+            for (int c = 0; c < size; c++)                  /* hood[0..] = (s0,l0), (s0,l1), (s0,l2), (s1,l0), ...  :737-747 */
+                for (int q = 0; q < size; q++) hood[n++] = src[rows[q] * nx + cols[c]];
+            qsort(hood, (size_t)n, sizeof(v3), median_compare);
+            dst[l * nx + s] = hood[(n - 1) / 2];                                          /* :719-723 */
+        }
+    }
+}
+
 uint64_t oracle_fnv1a(const void* data, size_t n_bytes)
 {
     const unsigned char* p = (const unsigned char*)data;

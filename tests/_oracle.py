@@ -27,6 +27,7 @@ class Oracle:
         lib.oracle_texture_values.argtypes = [P(A.PtSceneDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         lib.oracle_aabb_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
         lib.oracle_libm.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.oracle_median_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.oracle_fnv1a.argtypes = [C.c_void_p, C.c_size_t]
         lib.oracle_fnv1a.restype = C.c_uint64
 
@@ -58,6 +59,12 @@ class Oracle:
         rays = np.zeros(capacity, RAY_DTYPE)
         n = self.lib.oracle_record_rays(desc.ptr, nx, ny, max_depth, rays.ctypes.data, capacity)
         return rays[:n].copy()
+
+    def median_filter(self, image, size=3):
+        img = np.ascontiguousarray(image, np.float32)
+        out = np.empty_like(img)
+        self.lib.oracle_median_filter(img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0], size)
+        return out
 
     def pcg_stream(self, seed, n):
         out = np.empty(n, np.float32)

@@ -254,3 +254,66 @@ def test_cli_writes_every_image_format(tmp_path, oracle):
     assert r.returncode != 0 and "no CPU path" in r.stderr
     r = subprocess.run([exe, "--scene", "nope", "-q"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown scene" in r.stderr
+
+
+def tie_image(rng, ny, nx):
+    """Frame with many equal squared lengths carried by different colours (channel permutations of
+    small integers add up exactly), flat regions and ordinary noise: exercises the tie rule."""
+    base = rng.integers(0, 4, (ny, nx, 3)).astype(np.float32)
+    perm = rng.integers(0, 3, (ny, nx))
+    img = np.stack([np.take_along_axis(base, ((perm + k) % 3)[..., None], 2)[..., 0] for k in range(3)], 2)
+    img[: ny // 3] = rng.random((ny // 3, nx, 3), dtype=np.float32)
+    img[ny // 3: ny // 3 + 4, : nx // 2] = 0.25
+    return np.ascontiguousarray(img, np.float32)
+
+
+@pytest.mark.parametrize("size", [3, 2])
+@pytest.mark.parametrize("ny,nx", [(37, 53), (1, 1), (1, 9), (8, 1), (64, 64), (130, 257)])
+def test_median_filter_bit_exact(oracle, ny, nx, size):
+    """pt_median_filter against the reference's filter restated over the C library's qsort
+    (src/ptMain.cu:700-788).  Parity unpinned: the reference holds no filtered image."""
+    img = tie_image(np.random.default_rng(ny * 1000 + nx), ny, nx)
+    assert_bit_exact(pt.median_filter(img, size), oracle.median_filter(img, size), "median %dx%d size %d" % (nx, ny, size))
+
+
+def test_median_filter_full_frame_properties(oracle):
+    """1024x1024: a constant frame is a fixed point, every output pixel is one of its neighbours,
+    and a rendered frame filters to the oracle's result."""
+    flat = np.full((1024, 1024, 3), 0.5, np.float32)
+    assert_bit_exact(pt.median_filter(flat), flat, "constant frame")
+    d = pt.builtin_scene("cornell", 1.0)
+    frame = pt.Scene(d).render(1024, 1024, 4)
+    got = pt.median_filter(frame)
+    assert_bit_exact(got, oracle.median_filter(frame), "rendered frame")
+    with pytest.raises(pt.PtError):
+        pt.median_filter(frame, size=5)
+
+
+def test_stream_scene_renders_like_the_built_in(oracle):
+    """Scene -> the reference's byte stream -> scene: same image on the GPU, list walk and LBVH."""
+    for name, aspect, nx, ny, ns in (("cornell", 1.0, 64, 64, 8), ("random", 2.0, 80, 40, 4), ("simple_light", 2.0, 64, 32, 8)):
+        d = pt.builtin_scene(name, aspect)
+        blob, _ = pt.scene_to_stream(d)
+        d2 = pt.scene_from_stream(blob)
+        ref = oracle.render(d, nx, ny, ns)
+        assert_bit_exact(pt.Scene(d2).render(nx, ny, ns), ref, name + " via stream")
+    d3 = pt.scene_from_stream(pt.scene_to_stream(pt.builtin_scene("random", 2.0))[0], accel=abi.ACCEL_LBVH)
+    assert_bit_exact(pt.Scene(d3).render(80, 40, 4), oracle.render(pt.builtin_scene("random", 2.0), 80, 40, 4), "random via stream, LBVH")
+
+
+def test_cli_median_and_stream_options(tmp_path, oracle):
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(HERE), "gpupathtracer_amd", "ptrace")
+    blob_path, out1, out2 = str(tmp_path / "scene.bin"), str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    r = subprocess.run([exe, "--scene", "cornell", "-w", "40", "-h", "40", "-n", "4", "-m", "--stream-out", blob_path, "-f", out1],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = pt.builtin_scene("cornell", 1.0)
+    assert open(blob_path, "rb").read() == pt.scene_to_stream(d)[0]
+    want = oracle.median_filter(oracle.render(d, 40, 40, 4))
+    want8 = np.clip((255.99 * want.astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(np.asarray(Image.open(out1).convert("RGB")), want8)
+    r = subprocess.run([exe, "--stream-in", blob_path, "-w", "40", "-h", "40", "-n", "4", "-m", "-f", out2], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_array_equal(np.asarray(Image.open(out2).convert("RGB")), want8)

@@ -1,0 +1,121 @@
+"""The reference's scene byte stream (src/ptStream.cu, every serialize/deserialize member) read into
+and written from the flat scene description.  CPU only: host code of the library plus the oracle.
+
+Pins: the survey of the reference recorded the size of world->serialize for random_scene
+(27 276 bytes) and cornell_box (1 024 bytes); the writer must produce exactly those."""
+import struct
+
+import numpy as np
+import pytest
+
+import gpupathtracer_amd as pt
+from gpupathtracer_amd import abi
+
+SCENES = [("cornell", 1.0), ("random", 2.0), ("simple_spheres", 2.0), ("simple_light", 2.0), ("cornell_spheres", 1.0)]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def fourcc(s):
+    return struct.unpack("<i", s.encode())[0]
+
+
+def i32(*v):
+    return struct.pack("<%di" % len(v), *v)
+
+
+def f32(*v):
+    return struct.pack("<%df" % len(v), *v)
+
+
+def lamb(r, g, b):
+    return i32(fourcc("LAMB")) + i32(fourcc("CNST")) + f32(r, g, b)
+
+
+CAMERA = f32(*([0.0, 0.0, 5.0] + [-2.0, -1.0, 4.0] + [4.0, 0.0, 0.0] + [0.0, 2.0, 0.0] + [1, 0, 0] + [0, 1, 0] + [0, 0, 1] + [0.0, 1.0, 0.0]))
+SKY = i32(fourcc("SKYA"))
+
+
+def test_world_stream_sizes_match_the_reference_probe():
+    for name, aspect, want in (("random", 2.0, 27276), ("cornell", 1.0, 1024)):
+        blob, sections = pt.scene_to_stream(pt.builtin_scene(name, aspect))
+        assert sections[0] == want
+        assert sections[2] == 96                                 # 7 vectors + time0, time1, lens_radius
+        assert sum(sections) == len(blob)
+    blob, sections = pt.scene_to_stream(pt.builtin_scene("cornell", 1.0))
+    assert sections[1] == 28 and sections[3] == 16               # XZRectangle with a null material; CNST + colour
+    assert struct.unpack_from("<ii", blob, 0) == (1, 8)          # ListTypeId, count
+
+
+@pytest.mark.parametrize("name,aspect", SCENES)
+def test_round_trip_is_byte_and_image_identical(oracle, name, aspect):
+    d = pt.builtin_scene(name, aspect)
+    blob, _ = pt.scene_to_stream(d)
+    d2 = pt.scene_from_stream(blob)
+    blob2, _ = pt.scene_to_stream(d2)
+    assert blob2 == blob
+    assert d2.c.n_world == d.c.n_world and d2.c.n_lights == d.c.n_lights and d2.c.lights_is_list == d.c.lights_is_list
+    assert d2.c.n_materials <= d.c.n_materials                   # per-leaf copies are merged
+    a, b = oracle.render(d, 40, 24, 4), oracle.render(d2, 40, 24, 4)
+    assert (bits(a) == bits(b)).all()
+
+
+def test_final_scene_cannot_be_streamed():
+    with pytest.raises(pt.PtError) as e:
+        pt.scene_to_stream(pt.builtin_scene("final", 16 / 9))
+    assert e.value.code == abi.ERR_UNSUPPORTED
+
+
+def test_hand_written_stream_features(oracle):
+    """Nested lists flatten, FlipNormals toggles, a Translate's offset (written after its child) lands
+    on every leaf below it, a TriangleMesh record is skipped, a Box with a foreign child expands."""
+    sphere = lambda x, r: i32(2) + f32(x, 0.0, 0.0, r) + lamb(0.5, 0.5, 0.5)
+    rect = i32(4) + lamb(0.2, 0.3, 0.4) + f32(-1, 1, -1, 1, -2)                    # XYRectangle z=-2
+    mesh = i32(14) + i32(2) + b"\0" * 88
+    inner = i32(1) + i32(2) + sphere(0.0, 0.5) + i32(7) + i32(7) + i32(7) + rect   # list { sphere, flip^3(rect) }
+    odd_box = i32(8) + f32(0, 0, 0, 1, 1, 1) + sphere(3.0, 0.25)                   # Box whose child is a sphere
+    world = i32(1) + i32(4) + i32(9) + inner + f32(1.0, 2.0, 3.0) + mesh + odd_box + i32(-1)
+    blob = world + i32(-1) + CAMERA + SKY
+    desc = pt.scene_from_stream(blob)            # keep the owner alive while reading its arrays
+    d = desc.c
+    assert d.n_world == 3 and d.n_shapes == 3 and d.n_lights == 0 and d.ambient_type == abi.AMBIENT_SKY
+    s0, s1, s2 = d.shapes[0], d.shapes[1], d.shapes[2]
+    assert (s0.type, s0.flags, s0.xform_count) == (abi.SHAPE_SPHERE, 0, 1)
+    assert (s1.type, s1.flags, s1.xform_count) == (abi.SHAPE_RECT_XY, abi.FLIP_NORMAL, 1)
+    assert (s2.type, s2.xform_count) == (abi.SHAPE_SPHERE, 0)
+    for s in (s0, s1):
+        x = d.xforms[s.xform_first]
+        assert x.type == abi.XFORM_TRANSLATE and list(x.v) == [1.0, 2.0, 3.0]
+    assert d.n_materials == 2                                    # the two grey spheres share one record
+    assert list(d.camera)[:3] == [0.0, 0.0, 5.0]
+    # a stream the oracle can render: same picture as the equivalent hand-built world
+    img = oracle.render(pt.scene_from_stream(blob), 32, 16, 2)
+    assert np.isfinite(img).all() and img.max() > 0
+
+
+def test_constant_ambient_colour_follows_the_reference_device_side():
+    d = pt.builtin_scene("cornell", 1.0)
+    blob, sections = pt.scene_to_stream(d)
+    red = blob[:-12] + f32(1.0, 0.0, 0.0)
+    black = pt.scene_from_stream(red)
+    kept = pt.scene_from_stream(red, flags=abi.STREAM_KEEP_AMBIENT_COLOR)
+    assert list(black.c.ambient_color) == [0.0, 0.0, 0.0]
+    assert list(kept.c.ambient_color) == [1.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("blob,code", [
+    (b"", abi.ERR_INVALID),
+    (i32(1) + i32(1) + i32(99), abi.ERR_INVALID),                                  # unknown hitable id
+    (i32(1) + i32(1) + i32(12), abi.ERR_INVALID),                                  # BVH records are never written
+    (i32(1) + i32(1) + i32(2) + f32(0, 0, 0, 1) + i32(fourcc("NOPE")), abi.ERR_INVALID),
+    (i32(1) + i32(1) + i32(2) + f32(0, 0, 0, 1) + i32(fourcc("LAMB")) + i32(-1), abi.ERR_INVALID),   # null texture
+    (i32(1) + i32(0) + i32(-1) + CAMERA[:50], abi.ERR_INVALID),                    # truncated camera
+    (i32(1) + i32(1) + i32(9) + i32(11) + i32(2) + f32(0, 0, 0, 1) + lamb(1, 1, 1) + f32(0.1) +
+     i32(fourcc("ISOT")) + i32(fourcc("CNST")) + f32(1, 1, 1) + f32(0, 0, 0), abi.ERR_UNSUPPORTED),  # Translate(ConstantMedium)
+])
+def test_malformed_streams_are_errors(blob, code):
+    with pytest.raises(pt.PtError) as e:
+        pt.scene_from_stream(blob)
+    assert e.value.code == code
