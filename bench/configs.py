@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""The other BASELINE configurations on one GPU (the headline, Cornell 1024^2 x 4096, is bench.py):
+RTIOW 1920x1080 with the LBVH, the RTNW final scene, and the 2M-triangle height field in the
+Cornell enclosure.  Prints one JSON object per configuration; --quick cuts samples for a smoke run."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gpupathtracer_amd as pt                     # noqa: E402
+from gpupathtracer_amd import abi                  # noqa: E402
+
+
+def run(label, desc, nx, ny, spp, steps=2, **kw):
+    t0 = time.perf_counter()
+    sc = pt.Scene(desc)
+    pt.synchronize()
+    create_s = time.perf_counter() - t0
+    buf = pt.DeviceBuffer(nx * ny * 12)
+    sc.render_device(buf.ptr, nx, ny, max(1, spp // 16), 25, **kw)      # warm-up
+    pt.synchronize()
+    ms = []
+    for _ in range(steps):
+        sc.render_device(buf.ptr, nx, ny, spp, 25, **kw)
+        pt.synchronize()
+        ms.append(sc.stats().kernel_ms)
+    st = sc.stats()
+    k = min(ms)
+    out = {"config": label, "nx": nx, "ny": ny, "spp": spp, "kernel_ms": k, "Mpaths_per_s": nx * ny * spp / k / 1e3,
+           "scene_create_s": create_s, "lbvh_nodes": int(pt.library().pt_scene_lbvh_nodes(sc._h, None, 0)),
+           "schedule": st.schedule, "shapes": desc.c.n_shapes, "world": desc.c.n_world}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--grid", type=int, default=1000, help="height-field resolution (1000 -> 2 000 000 triangles)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    q = 16 if a.quick else 1
+    pt.set_device(0)
+    res = []
+    if a.only in ("", "c1"):
+        res.append(run("C1 random_scene 1920x1080 LBVH", pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 1024 // q))
+    if a.only in ("", "c1list"):
+        res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1))
+    if a.only in ("", "c3"):
+        res.append(run("C3 final 1920x1080", pt.builtin_scene("final", 16 / 9), 1920, 1080, 256 // q))
+    if a.only in ("", "c4"):
+        d = pt.trimesh_scene(a.grid, 16 / 9)
+        d.c.accel = abi.ACCEL_LBVH
+        res.append(run("C4 height field %d triangles in the Cornell enclosure 3840x2160 LBVH" % (2 * a.grid * a.grid), d, 3840, 2160, 64 // q, steps=1))
+    return res
+
+
+if __name__ == "__main__":
+    main()

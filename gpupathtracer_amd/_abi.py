@@ -16,7 +16,7 @@ STREAM_KEEP_AMBIENT_COLOR = 1
 ID_MISS = -1
 ID_MEDIUM_BASE = 0x40000000
 
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OOM = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OOM, ERR_CANCELLED = 0, -1, -2, -3, -4, -5, -6
 
 
 class PtShape(C.Structure):
@@ -104,7 +104,8 @@ assert C.sizeof(PtRenderParams) == 64
 # Every symbol include/ptcore.h declares.
 EXPORTS = [
     "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
-    "pt_trace_closest", "pt_render_stats", "pt_scene_lbvh_nodes", "pt_scene_desc_builtin",
+    "pt_trace_closest", "pt_render_stats", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
+    "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",
     "pt_median_filter", "pt_median_filter_device", "pt_device_count",
     "pt_set_device", "pt_device_synchronize", "pt_device_malloc", "pt_device_free", "pt_memcpy_to_host",

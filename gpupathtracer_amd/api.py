@@ -53,6 +53,11 @@ def library():
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
     lib.pt_scene_desc_free.restype = None
+    lib.pt_accum_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.pt_accum_bytes.restype = C.c_size_t
+    lib.pt_render_pass.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.pt_render_progressive.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_int32, PROGRESS_FN, C.c_void_p]
+    lib.pt_memcpy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.pt_median_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.pt_median_filter_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.pt_scene_desc_from_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, P(P(A.PtSceneDesc))]
@@ -91,6 +96,13 @@ def synchronize():
     _check(library().pt_device_synchronize())
 
 
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
+
+
+def accum_bytes(nx, ny):
+    return int(library().pt_accum_bytes(nx, ny))
+
+
 class DeviceBuffer:
     """Device memory owned by the library's HIP runtime."""
 
@@ -99,6 +111,11 @@ class DeviceBuffer:
         _check(library().pt_device_malloc(nbytes, C.byref(p)))
         self.ptr = p.value
         self.nbytes = nbytes
+
+    def from_host(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes == self.nbytes
+        _check(library().pt_memcpy_to_device(C.c_void_p(self.ptr), a.ctypes.data, a.nbytes))
 
     def to_host(self, dtype=np.float32):
         out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype)
@@ -281,6 +298,23 @@ class Scene:
         p = make_params(nx, ny, ns, max_depth, **kw)
         _check(library().pt_render_device(self._h, C.byref(p), C.c_void_p(d_out_ptr),
                                           C.c_void_p(stream) if stream else None))
+
+    def render_pass(self, d_accum_ptr, first_sample, n_samples, d_out_ptr, nx, ny, ns, max_depth=25, stream=None, **kw):
+        """Samples [first_sample, first_sample + n_samples) of a render of ns samples (device buffers)."""
+        p = make_params(nx, ny, ns, max_depth, **kw)
+        _check(library().pt_render_pass(self._h, C.byref(p), C.c_void_p(d_accum_ptr), first_sample, n_samples,
+                                        C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def render_progressive(self, nx, ny, ns, pass_samples, progress=None, max_depth=25, **kw):
+        """Whole render in passes; progress(done, total) returning True stops it.  Returns (image, cancelled)."""
+        p = make_params(nx, ny, ns, max_depth, **kw)
+        out = np.zeros((ny, nx, 3), np.float32)
+        cb = PROGRESS_FN((lambda done, total, user: 1 if progress(done, total) else 0) if progress else (lambda d, t, u: 0))
+        rc = library().pt_render_progressive(self._h, C.byref(p), out.ctypes.data, pass_samples, cb, None)
+        if rc == A.ERR_CANCELLED:
+            return out, True
+        _check(rc)
+        return out, False
 
     def stats(self):
         s = A.PtRenderStats()

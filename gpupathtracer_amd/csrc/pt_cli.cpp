@@ -4,7 +4,9 @@
 // -m/--median, -w/--width, -h/--height (height, not help), -n/--numsamples, -t/--threads,
 // -d/--maxdepth, -s/--stacksize, -f/--file; plus --scene, --gpus, --accel, --pipeline, which the
 // reference lacks (its scene is a source edit at src/ptMain.cu:559), and --stream-in / --stream-out,
-// which read and write the scene byte stream main() builds for its device (src/ptMain.cu:560-572).  The reference parses with
+// which read and write the scene byte stream main() builds for its device (src/ptMain.cu:560-572),
+// and --pass-samples K, which renders in passes of K samples and reports progress after each
+// (the reference's Progress display, src/ptMain.cu:663-677, on the GPU path).  The reference parses with
 // the vendored cxxopts; getopt_long gives the same short/long spellings here.
 #include <getopt.h>
 
@@ -34,7 +36,7 @@ int fail(const char* what)
 int main(int argc, char** argv)
 {
     bool quick = false, cpu = false, median = false;
-    int ns = 100, nx = 128 * 4, ny = 128 * 4, maxDepth = 25, gpus = 1;
+    int ns = 100, nx = 128 * 4, ny = 128 * 4, maxDepth = 25, gpus = 1, passSamples = 0;
     std::string outFile = "outputImage.ppm", scene = "random", accel = "auto", pipeline = "fused", streamIn, streamOut;
 
     static const option longopts[] = {
@@ -45,7 +47,8 @@ int main(int argc, char** argv)
         { "file", required_argument, nullptr, 'f' }, { "scene", required_argument, nullptr, 1000 },
         { "gpus", required_argument, nullptr, 1001 }, { "accel", required_argument, nullptr, 1002 },
         { "pipeline", required_argument, nullptr, 1003 }, { "stream-in", required_argument, nullptr, 1004 },
-        { "stream-out", required_argument, nullptr, 1005 }, { nullptr, 0, nullptr, 0 } };
+        { "stream-out", required_argument, nullptr, 1005 }, { "pass-samples", required_argument, nullptr, 1006 },
+        { nullptr, 0, nullptr, 0 } };
     int c;
     while ((c = getopt_long(argc, argv, "qcmw:h:n:t:d:s:f:", longopts, nullptr)) != -1) {
         switch (c) {
@@ -65,11 +68,12 @@ int main(int argc, char** argv)
         case 1003: pipeline = optarg; break;
         case 1004: streamIn = optarg; break;
         case 1005: streamOut = optarg; break;
+        case 1006: passSamples = std::atoi(optarg); break;
         default:
             std::cerr << "usage: ptrace [-q] [-w W] [-h H] [-n SPP] [-d DEPTH] [-f out.{ppm,hdr,png,tga,bmp}]\n"
                          "              [--scene simple_spheres|simple_light|random|cornell|cornell_spheres|final|trimesh]\n"
                          "              [--gpus N] [--accel auto|list|lbvh] [--pipeline fused|wavefront]\n"
-                         "              [--stream-in scene.bin] [--stream-out scene.bin] [-m]" << std::endl;
+                         "              [--stream-in scene.bin] [--stream-out scene.bin] [--pass-samples K] [-m]" << std::endl;
             return EXIT_FAILURE;
         }
     }
@@ -105,6 +109,32 @@ int main(int argc, char** argv)
     PtRenderParams p{};
     p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = maxDepth; p.shard_count = gpus; p.tile_w = 8; p.tile_h = 8;
     p.pipeline = (pipeline == "wavefront") ? PT_PIPELINE_WAVEFRONT : PT_PIPELINE_FUSED;
+
+    if (passSamples > 0 && gpus == 1) {          // one device, progress after every pass
+        PtScene* sc = nullptr;
+        std::cerr << "Allocating world...";
+        if (pt_set_device(0) != PT_OK || pt_scene_create(desc, &sc) != PT_OK) return fail("\nFailed to allocate world in GPU memory");
+        std::cerr << "done" << std::endl;
+        std::vector<float> image((size_t)3 * nx * ny);
+        auto report = [](int32_t done, int32_t total, void*) -> int {
+            std::cerr << "\rRendering world... " << (100 * (long)done / total) << "% (" << done << "/" << total << " samples)" << std::flush;
+            return 0;
+        };
+        if (pt_render_progressive(sc, &p, image.data(), passSamples, report, nullptr) != PT_OK) return fail("\nFailed to render on GPU");
+        std::cerr << std::endl;
+        pt_scene_destroy(sc);
+        pt_scene_desc_free(desc);
+        if (median) {
+            std::vector<float> filtered(image.size());
+            if (pt_median_filter(image.data(), filtered.data(), nx, ny, 3) != PT_OK) return fail("median filter");
+            image.swap(filtered);
+        }
+        std::string err;
+        if (!pt::write_image(outFile, image.data(), nx, ny, &err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }
+        std::cerr << "Done." << std::endl;
+        return EXIT_SUCCESS;
+    }
+    if (passSamples > 0) std::cerr << "--pass-samples applies to one GPU; rendering in one pass per device." << std::endl;
 
     std::cerr << "Allocating world...";
     std::vector<PtScene*> scenes((size_t)gpus, nullptr);

@@ -78,6 +78,13 @@ extern "C" int pt_memcpy_to_host(void* dst, const void* src, size_t bytes)
     return e == hipSuccess ? PT_OK : hip_err(e, "hipMemcpy");
 }
 
+extern "C" int pt_memcpy_to_device(void* dst, const void* src, size_t bytes)
+{
+    if (!dst || !src) { pt::set_error("pt_memcpy_to_device: null argument"); return PT_ERR_INVALID; }
+    hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    return e == hipSuccess ? PT_OK : hip_err(e, "hipMemcpy");
+}
+
 extern "C" int pt_comm_unique_id(void* id128)
 {
     if (!id128) { pt::set_error("pt_comm_unique_id: null argument"); return PT_ERR_INVALID; }

@@ -122,6 +122,44 @@ __global__ __launch_bounds__(256) void k_render_tiles(SceneView sv, RenderArgs r
     lane_write_pixel(st, ra, i, out);
 }
 
+// One pass of a progressive render: samples [first, first + count) of every owned pixel.  The
+// pixel's random stream and running sum wait in `acc` between passes (passes end on sample
+// boundaries, so no path is ever in flight), which makes any split into passes produce the
+// image of a single launch, and lets a host checkpoint `acc` and resume.  Each pass also
+// writes the estimate so far, sqrt(sum / samples done), the reference's normalisation
+// (src/ptMain.cu:163-166) applied to the samples that exist.
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
+                                                     int first, float* __restrict__ out)
+{
+    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wave_in_block;
+    if (wave >= ra.n_wave_tiles) return;
+    int x, ytop;
+    if (!wave_pixel(ra, wave, lane, x, ytop)) return;
+    int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    LaneState st;
+    lane_init(st);
+    unsigned i;
+    lane_begin_pixel(st, ra, x, ytop, i);
+    if (first > 0) {
+        const PtAccumPixel a = acc[i];
+        st.rng.state = ((uint64_t)a.rng_hi << 32) | a.rng_lo;
+        st.accum = mk(a.sum[0], a.sum[1], a.sum[2]);
+        st.s = first;
+    }
+    while (!lane_step<F>(sv, ra, st, fnx, fny, my_stack)) {}      // ra.ns = first + count for this launch
+    PtAccumPixel a;
+    a.rng_lo = (uint32_t)st.rng.state; a.rng_hi = (uint32_t)(st.rng.state >> 32);
+    a.sum[0] = st.accum.x; a.sum[1] = st.accum.y; a.sum[2] = st.accum.z;
+    a.samples = (uint32_t)ra.ns;
+    acc[i] = a;
+    lane_write_pixel(st, ra, i, out);
+}
+
 // Fused scheduler with persistent lanes: a lane that has finished its pixel takes the next pixel
 // slot of the shard (slots are numbered tile by tile, 64 per 8x8 wave tile) from a device counter,
 // so a wave stays full until the shard runs out.  Pays when the closest-hit search, whose loop is
@@ -211,6 +249,19 @@ void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float
     case 3: if (refill) hipLaunchKernelGGL(k_render_refill<M_TRIMESH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_TRIMESH>, grid, block, 0, st, sv, ra, out); break;
     case 4: if (refill) hipLaunchKernelGGL(k_render_refill<M_ALL>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_ALL>, grid, block, 0, st, sv, ra, out); break;
     default: if (refill) hipLaunchKernelGGL(k_render_refill<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out); break;
+    }
+}
+
+void launch_pass(int variant, const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, hipStream_t st)
+{
+    const dim3 block(256), grid((ra.n_wave_tiles + 3) / 4);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(k_render_pass<M_CORNELL>, grid, block, 0, st, sv, ra, acc, first, out); break;
+    case 1: hipLaunchKernelGGL(k_render_pass<M_SPHERES>, grid, block, 0, st, sv, ra, acc, first, out); break;
+    case 2: hipLaunchKernelGGL(k_render_pass<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, acc, first, out); break;
+    case 3: hipLaunchKernelGGL(k_render_pass<M_TRIMESH>, grid, block, 0, st, sv, ra, acc, first, out); break;
+    case 4: hipLaunchKernelGGL(k_render_pass<M_ALL>, grid, block, 0, st, sv, ra, acc, first, out); break;
+    default: hipLaunchKernelGGL(k_render_pass<M_ALL_LBVH>, grid, block, 0, st, sv, ra, acc, first, out); break;
     }
 }
 
@@ -470,6 +521,17 @@ bool make_args(const PtRenderParams* p, RenderArgs* ra)
 
 }  // namespace
 
+static uint64_t owned_pixels(const PtRenderParams* p, const RenderArgs& ra)
+{
+    uint64_t owned_px = 0;
+    for (int t = ra.shard_index; t < ra.n_tiles; t += ra.shard_count) {
+        const int ty = t / ra.tiles_x, tx = t % ra.tiles_x;
+        const int w = std::min(ra.tile_w, p->nx - tx * ra.tile_w), h = std::min(ra.tile_h, p->ny - ty * ra.tile_h);
+        owned_px += (uint64_t)w * (uint64_t)h;
+    }
+    return owned_px;
+}
+
 extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream)
 {
     if (!sc || !p || !d_out_rgb) { pt::set_error("pt_render_device: null argument"); return PT_ERR_INVALID; }
@@ -507,19 +569,71 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->have_timing = true;
-    // paths = owned pixels x ns
-    uint64_t owned_px = 0;
-    {
-        const int tiles_y = (p->ny + ra.tile_h - 1) / ra.tile_h;
-        for (int t = ra.shard_index; t < ra.n_tiles; t += ra.shard_count) {
-            const int ty = t / ra.tiles_x, tx = t % ra.tiles_x;
-            const int w = std::min(ra.tile_w, p->nx - tx * ra.tile_w), h = std::min(ra.tile_h, p->ny - ty * ra.tile_h);
-            owned_px += (uint64_t)w * (uint64_t)h;
-        }
-        (void)tiles_y;
-    }
-    sc->last.paths = owned_px * (uint64_t)p->ns;
+    sc->last.paths = owned_pixels(p, ra) * (uint64_t)p->ns;
     return PT_OK;
+}
+
+extern "C" size_t pt_accum_bytes(int32_t nx, int32_t ny)
+{
+    if (nx <= 0 || ny <= 0) return 0;
+    return (size_t)nx * (size_t)ny * sizeof(PtAccumPixel);
+}
+
+extern "C" int pt_render_pass(PtScene* sc, const PtRenderParams* p, void* d_accum, int32_t first_sample, int32_t n_samples,
+                              void* d_out_rgb, void* hip_stream)
+{
+    if (!sc || !p || !d_accum || !d_out_rgb) { pt::set_error("pt_render_pass: null argument"); return PT_ERR_INVALID; }
+    RenderArgs ra;
+    if (!make_args(p, &ra)) return PT_ERR_INVALID;
+    if (first_sample < 0 || n_samples <= 0 || (int64_t)first_sample + n_samples > (int64_t)p->ns) {
+        pt::set_error("pt_render_pass: the pass must lie inside [0, ns)"); return PT_ERR_INVALID;
+    }
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT) { pt::set_error("pt_render_pass: passes run on the fused pipeline"); return PT_ERR_UNSUPPORTED; }
+    ra.ns = first_sample + n_samples;                     // the launch stops, and normalises, at the samples done so far
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    float* out = static_cast<float*>(d_out_rgb);
+    if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
+    if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
+    if (first_sample == 0 &&
+        !hip_ok(hipMemsetAsync(d_accum, 0, pt_accum_bytes(p->nx, p->ny), st), "hipMemsetAsync(accumulators)")) return PT_ERR_HIP;
+    if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
+    sc->last = PtRenderStats{};
+    if (ra.n_wave_tiles > 0) launch_pass(sc->variant, sc->view, ra, static_cast<PtAccumPixel*>(d_accum), first_sample, out, st);
+    if (!hip_ok(hipGetLastError(), "render pass launch")) return PT_ERR_HIP;
+    sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
+    sc->last.pipeline = PT_PIPELINE_FUSED;
+    sc->last.schedule = PT_SCHEDULE_TILES;
+    if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
+    if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
+    sc->have_timing = true;
+    sc->last.paths = owned_pixels(p, ra) * (uint64_t)n_samples;
+    return PT_OK;
+}
+
+extern "C" int pt_render_progressive(PtScene* sc, const PtRenderParams* p, float* out_rgb, int32_t pass_samples,
+                                     PtProgressFn progress, void* user)
+{
+    if (!sc || !p || !out_rgb) { pt::set_error("pt_render_progressive: null argument"); return PT_ERR_INVALID; }
+    if (p->nx <= 0 || p->ny <= 0 || p->ns <= 0) { pt::set_error("render: nx, ny, ns must be positive"); return PT_ERR_INVALID; }
+    if (pass_samples <= 0) { pt::set_error("pt_render_progressive: pass_samples must be positive"); return PT_ERR_INVALID; }
+    const size_t bytes = (size_t)3 * p->nx * p->ny * sizeof(float);
+    void *d_out = nullptr, *d_acc = nullptr;
+    if (!hip_ok(hipMalloc(&d_out, bytes), "hipMalloc(frame)")) return PT_ERR_OOM;
+    if (!hip_ok(hipMalloc(&d_acc, pt_accum_bytes(p->nx, p->ny)), "hipMalloc(accumulators)")) { (void)hipFree(d_out); return PT_ERR_OOM; }
+    int rc = PT_OK;
+    bool cancelled = false;
+    for (int32_t first = 0; first < p->ns && rc == PT_OK && !cancelled; first += pass_samples) {
+        const int32_t n = std::min(pass_samples, p->ns - first);
+        rc = pt_render_pass(sc, p, d_acc, first, n, d_out, nullptr);
+        if (rc == PT_OK && !hip_ok(hipStreamSynchronize(nullptr), "render pass (synchronize)")) rc = PT_ERR_HIP;
+        if (rc == PT_OK && progress && progress(first + n, p->ns, user) != 0) cancelled = true;
+    }
+    // a cancelled render still hands back the estimate of the samples it finished
+    if (rc == PT_OK && !hip_ok(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy(frame)")) rc = PT_ERR_HIP;
+    (void)hipFree(d_out);
+    (void)hipFree(d_acc);
+    if (rc == PT_OK && cancelled) { pt::set_error("pt_render_progressive: cancelled by the progress callback"); return PT_ERR_CANCELLED; }
+    return rc;
 }
 
 extern "C" int pt_render(PtScene* sc, const PtRenderParams* p, float* out_rgb)

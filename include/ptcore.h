@@ -208,7 +208,7 @@ typedef struct PtScene PtScene;
  * prints to std::cerr and returns EXIT_FAILURE instead (src/ptMain.cu:606-610,642-646). */
 enum PtError {
     PT_OK = 0, PT_ERR_INVALID = -1, PT_ERR_NO_DEVICE = -2, PT_ERR_HIP = -3,
-    PT_ERR_UNSUPPORTED = -4, PT_ERR_OOM = -5
+    PT_ERR_UNSUPPORTED = -4, PT_ERR_OOM = -5, PT_ERR_CANCELLED = -6
 };
 const char* pt_last_error(void);
 
@@ -235,6 +235,35 @@ int  pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, int32_t* prim
 
 /* Fills *stats with the timings of the scene's most recent render call; waits for it. */
 int  pt_render_stats(PtScene* scene, PtRenderStats* stats);
+
+/* ---- progressive accumulation ----------------------------------------------------------------
+ * The reference renders all ns samples of a pixel in one kernel and only counts finished pixels
+ * for a progress display (int* progress, src/ptMain.cu:171,186-188; the poller at :616-640 is
+ * commented out).  Here a render may be cut into passes of whole samples: between passes each
+ * pixel's PCG state and running sum wait in a PtAccumPixel array in device memory, so the
+ * passes add up to exactly the image of one pt_render_device call, a host can show the estimate
+ * after every pass (out holds sqrt(sum / samples so far), src/ptMain.cu:163-166), and the array
+ * can be copied out and back (pt_memcpy_to_host / pt_memcpy_to_device) to checkpoint and resume
+ * a long render.  Passes run on the fused pipeline with one pixel per lane. */
+typedef struct PtAccumPixel {
+    uint32_t rng_lo, rng_hi;   /* PcgRng state (include/ptRNG.h:96-134); its increment follows from the pixel index */
+    float    sum[3];           /* accumCol so far (src/ptMain.cu:156-161) */
+    uint32_t samples;          /* samples in sum */
+} PtAccumPixel;                /* 24 bytes */
+
+/* Bytes of the accumulator array for an nx*ny frame (device memory, caller-allocated). */
+size_t pt_accum_bytes(int32_t nx, int32_t ny);
+/* Samples [first_sample, first_sample + n_samples) of every pixel this shard owns; params->ns is
+ * the total the render is heading for.  first_sample == 0 clears d_accum first; otherwise d_accum
+ * must hold the state left by the passes up to first_sample.  d_out_rgb receives the estimate. */
+int  pt_render_pass(PtScene* scene, const PtRenderParams* params, void* d_accum,
+                    int32_t first_sample, int32_t n_samples, void* d_out_rgb, void* hip_stream);
+/* Whole render in passes of pass_samples with a callback after each (samples done, total, user);
+ * a non-zero return stops the render: out_rgb then holds the estimate so far and the call
+ * returns PT_ERR_CANCELLED. */
+typedef int (*PtProgressFn)(int32_t samples_done, int32_t samples_total, void* user);
+int  pt_render_progressive(PtScene* scene, const PtRenderParams* params, float* out_rgb,
+                           int32_t pass_samples, PtProgressFn progress, void* user);
 
 /* Copies the library-built LBVH (64-byte nodes: two child boxes and two child links) to the host:
  * returns the node count, or a negative error; nodes may be NULL to query the count. */
@@ -296,6 +325,7 @@ int  pt_device_synchronize(void);
 int  pt_device_malloc(size_t bytes, void** out_device_ptr);
 void pt_device_free(void* device_ptr);
 int  pt_memcpy_to_host(void* host_dst, const void* device_src, size_t bytes);
+int  pt_memcpy_to_device(void* device_dst, const void* host_src, size_t bytes);
 
 /* ---- one-node multi-GPU frame exchange over RCCL ------------------------------------------ */
 /* No counterpart in the reference (single device, no communication library).  One process per

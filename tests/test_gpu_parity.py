@@ -314,6 +314,48 @@ def test_cli_median_and_stream_options(tmp_path, oracle):
     want = oracle.median_filter(oracle.render(d, 40, 40, 4))
     want8 = np.clip((255.99 * want.astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)
     np.testing.assert_array_equal(np.asarray(Image.open(out1).convert("RGB")), want8)
-    r = subprocess.run([exe, "--stream-in", blob_path, "-w", "40", "-h", "40", "-n", "4", "-m", "-f", out2], capture_output=True, text=True)
+    r = subprocess.run([exe, "--stream-in", blob_path, "-w", "40", "-h", "40", "-n", "4", "-m", "-f", out2, "--pass-samples", "3"],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    assert "100% (4/4 samples)" in r.stderr
     np.testing.assert_array_equal(np.asarray(Image.open(out2).convert("RGB")), want8)
+
+
+def test_progressive_passes_equal_one_launch(oracle):
+    """Passes of whole samples add up to the single-launch image bit for bit; every pass's estimate is
+    the image of a render that stops there; the accumulators survive a trip through the host into a
+    new scene object (checkpoint / resume); uneven and sharded passes too."""
+    nx, ny, ns = 72, 40, 11
+    for name, aspect, kw in (("cornell", nx / ny, {}), ("final", nx / ny, {}), ("random", nx / ny, {"accel": abi.ACCEL_LBVH})):
+        d = pt.builtin_scene(name, aspect, **kw)
+        sc = pt.Scene(d)
+        ref = {n: oracle.render(d, nx, ny, n) for n in (4, 5, 11)}
+        frame, acc = pt.DeviceBuffer(nx * ny * 12), pt.DeviceBuffer(pt.accum_bytes(nx, ny))
+        sc.render_pass(acc.ptr, 0, 4, frame.ptr, nx, ny, ns); pt.synchronize()
+        assert_bit_exact(frame.to_host().reshape(ny, nx, 3), ref[4], name + " estimate after 4 samples")
+        sc.render_pass(acc.ptr, 4, 1, frame.ptr, nx, ny, ns); pt.synchronize()
+        assert_bit_exact(frame.to_host().reshape(ny, nx, 3), ref[5], name + " estimate after 5 samples")
+        saved = acc.to_host(np.uint32).copy()                       # checkpoint
+        assert (saved.reshape(-1, 6)[:, 5] == 5).all()
+        del sc
+        sc2 = pt.Scene(d)                                           # resume in a fresh scene object
+        acc2, frame2 = pt.DeviceBuffer(pt.accum_bytes(nx, ny)), pt.DeviceBuffer(nx * ny * 12)
+        acc2.from_host(saved)
+        sc2.render_pass(acc2.ptr, 5, 6, frame2.ptr, nx, ny, ns); pt.synchronize()
+        assert_bit_exact(frame2.to_host().reshape(ny, nx, 3), ref[11], name + " resumed render")
+        assert sc2.stats().paths == nx * ny * 6
+    d = pt.builtin_scene("cornell", nx / ny)
+    sc = pt.Scene(d)
+    seen = []
+    img, cancelled = sc.render_progressive(nx, ny, ns, 3, progress=lambda done, total: seen.append((done, total)) or False)
+    assert not cancelled and seen == [(3, 11), (6, 11), (9, 11), (11, 11)]
+    assert_bit_exact(img, oracle.render(d, nx, ny, ns), "progressive, passes of 3")
+    img, cancelled = sc.render_progressive(nx, ny, ns, 4, progress=lambda done, total: done >= 8)
+    assert cancelled
+    assert_bit_exact(img, oracle.render(d, nx, ny, 8), "cancelled after 8 samples")
+    part = sc.render_progressive(nx, ny, ns, 5, shard_index=1, shard_count=3, tile=(16, 8))[0]
+    assert_bit_exact(part, oracle.render(d, nx, ny, ns, shard_index=1, shard_count=3, tile=(16, 8)), "progressive shard")
+    frame, acc = pt.DeviceBuffer(nx * ny * 12), pt.DeviceBuffer(pt.accum_bytes(nx, ny))
+    for bad in ((-1, 2), (0, 0), (10, 2)):
+        with pytest.raises(pt.PtError):
+            sc.render_pass(acc.ptr, bad[0], bad[1], frame.ptr, nx, ny, ns)
