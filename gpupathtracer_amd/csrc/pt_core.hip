@@ -105,14 +105,14 @@ __device__ __forceinline__ void lane_init(LaneState& st)
 template <uint32_t F>
 __global__ __launch_bounds__(256) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
 {
-    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wave_in_block;
     if (wave >= ra.n_wave_tiles) return;
     int x, ytop;
     if (!wave_pixel(ra, wave, lane, x, ytop)) return;
-    int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
     const float fnx = (float)ra.nx, fny = (float)ra.ny;
     LaneState st;
     lane_init(st);
@@ -132,14 +132,14 @@ template <uint32_t F>
 __global__ __launch_bounds__(256) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
                                                      int first, float* __restrict__ out)
 {
-    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wave_in_block;
     if (wave >= ra.n_wave_tiles) return;
     int x, ytop;
     if (!wave_pixel(ra, wave, lane, x, ytop)) return;
-    int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
     const float fnx = (float)ra.nx, fny = (float)ra.ny;
     LaneState st;
     lane_init(st);
@@ -169,10 +169,10 @@ template <uint32_t F>
 __global__ __launch_bounds__(256) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
                                                        unsigned* __restrict__ next_slot)
 {
-    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
-    int* my_stack = (F & F_LBVH) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
     const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
     const float fnx = (float)ra.nx, fny = (float)ra.ny;
     LaneState st;
@@ -205,10 +205,10 @@ template <uint32_t F>
 __global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay* __restrict__ rays, size_t n,
                                                        int32_t* __restrict__ prim_id, float* __restrict__ t_out)
 {
-    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int* my_stack = (F & F_LBVH) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
     const PtRay pr = rays[i];
     Ray r;
     r.o = mk(pr.o[0], pr.o[1], pr.o[2]);

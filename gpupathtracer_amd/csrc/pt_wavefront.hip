@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void k_wf_init(SceneView sv, RenderArgs ra, Wf
 template <uint32_t F>
 __global__ __launch_bounds__(256) void k_wf_extend(SceneView sv, RenderArgs ra, WfState w, int parity, float* __restrict__ out)
 {
-    __shared__ int lds_stack[(F & F_LBVH) ? 4 * 64 * LBVH_LDS_STACK : 1];
-    int* my_stack = (F & F_LBVH) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
     const unsigned count = w.counts[C_EXT0 + parity];
     const unsigned stride = gridDim.x * blockDim.x;
     // whole waves iterate together so the ballots in queue_push see every lane of the wave
