@@ -119,3 +119,40 @@ def test_malformed_streams_are_errors(blob, code):
     with pytest.raises(pt.PtError) as e:
         pt.scene_from_stream(blob)
     assert e.value.code == code
+
+
+def test_mutated_streams_never_crash():
+    """Byte-level damage to valid streams: the reader either refuses the stream or yields a description
+    that pt_scene_create's validation can judge (PT_ERR_INVALID, or PT_ERR_NO_DEVICE / success when
+    the description is sound) -- never a fault."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    lib = pt.library()
+    blobs = [pt.scene_to_stream(pt.builtin_scene(n, a))[0] for n, a in (("cornell", 1.0), ("simple_light", 2.0), ("cornell_spheres", 1.0))]
+    outcomes = {"refused": 0, "accepted": 0}
+    for trial in range(1500):
+        b = bytearray(blobs[trial % len(blobs)])
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 3))
+            if len(b) < 8:
+                break
+            pos = int(rng.integers(0, len(b)))
+            if kind == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[pos - pos % 4: pos - pos % 4 + 4] = i32(int(rng.integers(-2, 16)))
+            else:
+                del b[pos:]
+        try:
+            d = pt.scene_from_stream(bytes(b))
+        except pt.PtError as e:
+            assert e.code in (abi.ERR_INVALID, abi.ERR_UNSUPPORTED)
+            outcomes["refused"] += 1
+            continue
+        outcomes["accepted"] += 1
+        h = C.c_void_p()
+        rc = lib.pt_scene_create(d.ptr, C.byref(h))
+        assert rc in (abi.OK, abi.ERR_INVALID, abi.ERR_NO_DEVICE, abi.ERR_UNSUPPORTED)
+        if rc == abi.OK:
+            lib.pt_scene_destroy(h)
+    assert outcomes["refused"] > 100 and outcomes["accepted"] > 100
