@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--cpu-spp", type=int, default=512, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles",
+                    help="tiles: whole pixels per rank, the reference's image bit for bit (default).  samples: every rank "
+                         "traces spp/N samples of every pixel from its own seeds -- not the reference's random sequence, "
+                         "equal to it up to sampling noise")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,8 +103,15 @@ def main():
 
     kernel_ms = []
 
+    by_samples = args.shard == "samples" and world > 1
+    if by_samples and args.spp % world:
+        raise SystemExit("bench.py: --shard samples needs spp divisible by the number of GPUs")
+
     def step(record):
-        scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, shard_index=rank, shard_count=world, tile=(8, 8))
+        if by_samples:        # raw sums of this rank's batch; added by the reduce, averaged + gamma'd once on the root
+            scene.render_device(frame.ptr, nx, ny, args.spp // world, args.depth, batch_index=rank, batch_count=world, raw_sum=1)
+        else:
+            scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, shard_index=rank, shard_count=world, tile=(8, 8))
         if record:
             kernel_ms.append(scene.stats().kernel_ms)      # HIP events on the launch stream
         if world > 1:
@@ -110,6 +121,10 @@ def main():
                 import torch
                 host = torch.from_numpy(frame.to_host())
                 dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if by_samples and rank == 0:
+                    frame.from_host(host.numpy())
+            if by_samples and rank == 0:
+                pt.frame_finish(frame.ptr, n_floats, args.spp)
 
     def barrier():
         if dist is not None:
@@ -170,7 +185,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s_box %dx%d %dspp depth%d (BASELINE configs[2])" % (args.scene, nx, ny, args.spp, args.depth)
                        if args.scene == "cornell" else "%s %dx%d %dspp depth%d" % (args.scene, nx, ny, args.spp, args.depth),
-                       "sharding": "8x8 pixel tiles round-robin over ranks", "pipeline": "fused", "collective": collective},
+                       "sharding": ("sample batches per rank (own seeds: not the reference's sequence)" if by_samples
+                                    else "8x8 pixel tiles round-robin over ranks"),
+                       "pipeline": "fused", "collective": collective},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     if comm is not None:

@@ -83,7 +83,8 @@ class PtRenderParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("ns", C.c_int32), ("max_depth", C.c_int32),
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32),
-                ("pipeline", C.c_int32), ("schedule", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("pipeline", C.c_int32), ("schedule", C.c_int32), ("batch_index", C.c_int32), ("batch_count", C.c_int32),
+                ("raw_sum", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class PtRay(C.Structure):
@@ -104,7 +105,7 @@ assert C.sizeof(PtRenderParams) == 64
 # Every symbol include/ptcore.h declares.
 EXPORTS = [
     "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
-    "pt_trace_closest", "pt_render_stats", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
+    "pt_trace_closest", "pt_render_stats", "pt_frame_finish_device", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
     "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",
     "pt_median_filter", "pt_median_filter_device", "pt_device_count",

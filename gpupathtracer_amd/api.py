@@ -53,6 +53,7 @@ def library():
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
     lib.pt_scene_desc_free.restype = None
+    lib.pt_frame_finish_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
     lib.pt_accum_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.pt_accum_bytes.restype = C.c_size_t
     lib.pt_render_pass.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -97,6 +98,10 @@ def synchronize():
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
+
+
+def frame_finish(d_frame_ptr, n_floats, total_samples, stream=None):
+    _check(library().pt_frame_finish_device(C.c_void_p(d_frame_ptr), n_floats, total_samples, C.c_void_p(stream)))
 
 
 def accum_bytes(nx, ny):
@@ -260,9 +265,11 @@ class RenderStats:
         self.schedule = int(s.schedule)
 
 
-def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0):
+def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0,
+                batch_index=0, batch_count=0, raw_sum=0):
     return A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=shard_index,
-                            shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline, schedule=schedule)
+                            shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline, schedule=schedule,
+                            batch_index=batch_index, batch_count=batch_count, raw_sum=raw_sum)
 
 
 class Scene:

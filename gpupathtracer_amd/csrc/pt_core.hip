@@ -40,7 +40,7 @@ __device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs
     st.x = x;
     st.y = ra.ny - 1 - ytop;                              // row 0 of the image is the top
     i = (unsigned)(ytop * ra.nx + x);                     // = (ny - y - 1) * nx + x   (src/ptMain.cu:178)
-    st.rng.seed(i);                                       // PcgRng rng(i)              (src/ptMain.cu:183)
+    st.rng.seed((uint64_t)i + ra.seed_offset);            // PcgRng rng(i)              (src/ptMain.cu:183)
     st.accum = mk(0, 0, 0);
     st.s = 0;
     st.fresh = true;
@@ -86,6 +86,10 @@ __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs&
 
 __device__ __forceinline__ void lane_write_pixel(const LaneState& st, const RenderArgs& ra, unsigned i, float* __restrict__ out)
 {
+    if (ra.raw_sum) {                                     // a sample batch: sums are added across batches, finished later
+        out[3 * (size_t)i + 0] = st.accum.x; out[3 * (size_t)i + 1] = st.accum.y; out[3 * (size_t)i + 2] = st.accum.z;
+        return;
+    }
     const float inv_ns = 1 / (float)ra.ns;                // accumCol /= float(ns): reciprocal, then multiplies
     out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, st.accum.x * inv_ns));
     out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, st.accum.y * inv_ns));
@@ -516,6 +520,10 @@ bool make_args(const PtRenderParams* p, RenderArgs* ra)
     const int owned = (ra->n_tiles - p->shard_index + sc - 1) / sc;     // tiles t with t % sc == shard_index
     ra->n_wave_tiles = owned * ra->sub_x * ra->sub_y;
     ra->refill = 0;
+    if (p->batch_count < 0 || p->batch_index < 0 || (p->batch_count > 0 && p->batch_index >= p->batch_count) ||
+        (p->batch_count == 0 && p->batch_index != 0)) return fail("render: batch_index out of range");
+    ra->seed_offset = (uint64_t)p->batch_index * (uint64_t)p->nx * (uint64_t)p->ny;
+    ra->raw_sum = p->raw_sum ? 1 : 0;
     return true;
 }
 
@@ -554,6 +562,9 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->last = PtRenderStats{};
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT && (ra.seed_offset != 0 || ra.raw_sum)) {
+        pt::set_error("render: sample batches run on the fused pipeline"); return PT_ERR_UNSUPPORTED;
+    }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT) {
         const int rc = pt::render_wavefront(sc, ra, out, st);       // host-driven rounds; blocks
         if (rc != PT_OK) return rc;
@@ -570,6 +581,23 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->have_timing = true;
     sc->last.paths = owned_pixels(p, ra) * (uint64_t)p->ns;
+    return PT_OK;
+}
+
+__global__ __launch_bounds__(256) void k_frame_finish(float* __restrict__ frame, size_t n, float inv_ns)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) frame[i] = sqrtf(fmaxf(0.0f, frame[i] * inv_ns));
+}
+
+extern "C" int pt_frame_finish_device(void* d_frame, size_t n_floats, int32_t total_samples, void* hip_stream)
+{
+    if (!d_frame || total_samples <= 0) { pt::set_error("pt_frame_finish_device: bad arguments"); return PT_ERR_INVALID; }
+    if (n_floats == 0) return PT_OK;
+    const float inv_ns = 1 / (float)total_samples;
+    hipLaunchKernelGGL(k_frame_finish, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<float*>(d_frame), n_floats, inv_ns);
+    if (!hip_ok(hipGetLastError(), "frame finish launch")) return PT_ERR_HIP;
     return PT_OK;
 }
 

@@ -179,7 +179,17 @@ typedef struct PtRenderParams {
     int32_t tile_w, tile_h;
     int32_t pipeline;     /* PtPipeline */
     int32_t schedule;     /* PtSchedule (fused pipeline only) */
-    int32_t reserved[6];
+    /* Sample batches: NOT the reference's random sequence.  The reference runs one PCG stream per
+     * pixel through all ns samples (src/ptMain.cu:156-162,183), so only whole pixels can be dealt
+     * to different GPUs without changing the image.  With batch_count > 1 this call instead traces
+     * ns samples of batch batch_index, seeding pixel i with i + batch_index * nx * ny (batch 0 is
+     * the reference's stream), so that several GPUs can each take part of a pixel's samples;
+     * the batches' images differ from the reference's by sampling noise only.  With raw_sum != 0
+     * out_rgb receives the plain sums of the samples (no averaging, no sqrt) so that batches can
+     * be added and finished once with pt_frame_finish_device.  Fused pipeline only. */
+    int32_t batch_index, batch_count;
+    int32_t raw_sum;
+    int32_t reserved[3];
 } PtRenderParams;
 
 /* One ray for pt_trace_closest.  The hit range is the integrator's [0.001, FLT_MAX]
@@ -235,6 +245,10 @@ int  pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, int32_t* prim
 
 /* Fills *stats with the timings of the scene's most recent render call; waits for it. */
 int  pt_render_stats(PtScene* scene, PtRenderStats* stats);
+
+/* frame[i] = sqrt(max(0, frame[i] * (1 / total_samples))) over n_floats device floats: the
+ * averaging and gamma of render_pixel (src/ptMain.cu:163-166) for a frame of raw sums. */
+int  pt_frame_finish_device(void* d_frame, size_t n_floats, int32_t total_samples, void* hip_stream);
 
 /* ---- progressive accumulation ----------------------------------------------------------------
  * The reference renders all ns samples of a pixel in one kernel and only counts finished pixels

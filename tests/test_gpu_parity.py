@@ -359,3 +359,34 @@ def test_progressive_passes_equal_one_launch(oracle):
     for bad in ((-1, 2), (0, 0), (10, 2)):
         with pytest.raises(pt.PtError):
             sc.render_pass(acc.ptr, bad[0], bad[1], frame.ptr, nx, ny, ns)
+
+
+def test_sample_batches_are_a_labelled_departure(oracle):
+    """Sample batches reseed each pixel per batch, so they are NOT the reference's image: batch 0 alone
+    is (same stream), the sum of several batches differs from the one-stream render by sampling noise
+    only.  Tolerance: PSNR >= 30 dB between the 4x64-sample batch image and the 256-sample reference
+    stream image of the Cornell box at 96x96 (two independent 256-sample renders sit near 33 dB)."""
+    nx = ny = 96
+    d = pt.builtin_scene("cornell", 1.0)
+    sc = pt.Scene(d)
+    ref64 = oracle.render(d, nx, ny, 64)
+    assert_bit_exact(sc.render(nx, ny, 64, batch_index=0, batch_count=4), ref64, "batch 0 is the reference stream")
+    frame, total = pt.DeviceBuffer(nx * ny * 12), np.zeros((ny, nx, 3), np.float32)
+    for b in range(4):
+        sc.render_device(frame.ptr, nx, ny, 64, batch_index=b, batch_count=4, raw_sum=1); pt.synchronize()
+        part = frame.to_host().reshape(ny, nx, 3)
+        if b == 0:
+            fin = pt.DeviceBuffer(nx * ny * 12); fin.from_host(part)
+            pt.frame_finish(fin.ptr, nx * ny * 3, 64); pt.synchronize()
+            assert_bit_exact(fin.to_host().reshape(ny, nx, 3), ref64, "raw sums of batch 0, finished")
+        total += part
+    acc = pt.DeviceBuffer(nx * ny * 12); acc.from_host(total)
+    pt.frame_finish(acc.ptr, nx * ny * 3, 256); pt.synchronize()
+    batched = acc.to_host().reshape(ny, nx, 3)
+    ref256 = oracle.render(d, nx, ny, 256)
+    assert not np.array_equal(batched, ref256)
+    assert _oracle.psnr(batched, ref256) >= 30.0
+    with pytest.raises(pt.PtError):
+        sc.render(nx, ny, 4, batch_index=4, batch_count=4)
+    with pytest.raises(pt.PtError):
+        sc.render(nx, ny, 4, batch_index=1, batch_count=2, pipeline=abi.PIPELINE_WAVEFRONT)
