@@ -7,11 +7,11 @@ library has not been built -- there is no CPU fallback.
 """
 from .api import (  # noqa: F401
     PtError, Scene, SceneDesc, RenderStats, DeviceBuffer, Comm, builtin_scene, trimesh_scene,
-    scene_from_stream, scene_to_stream, median_filter, accum_bytes, frame_finish,
+    scene_from_stream, scene_to_stream, median_filter, accum_bytes, frame_finish, render_on_devices,
     device_count, set_device, synchronize, libm_eval, library, library_path,
 )
 from . import _abi as abi  # noqa: F401
 
 __all__ = ["PtError", "Scene", "SceneDesc", "RenderStats", "DeviceBuffer", "Comm", "builtin_scene",
-           "trimesh_scene", "scene_from_stream", "scene_to_stream", "median_filter", "accum_bytes", "frame_finish", "device_count", "set_device", "synchronize", "libm_eval", "library",
+           "trimesh_scene", "scene_from_stream", "scene_to_stream", "median_filter", "accum_bytes", "frame_finish", "render_on_devices", "device_count", "set_device", "synchronize", "libm_eval", "library",
            "library_path", "abi"]

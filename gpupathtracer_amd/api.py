@@ -53,6 +53,7 @@ def library():
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
     lib.pt_scene_desc_free.restype = None
+    lib.pt_render_on_devices.argtypes = [P(A.PtSceneDesc), P(A.PtRenderParams), P(C.c_int32), C.c_int32, C.c_void_p]
     lib.pt_frame_finish_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
     lib.pt_accum_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.pt_accum_bytes.restype = C.c_size_t
@@ -98,6 +99,15 @@ def synchronize():
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
+
+
+def render_on_devices(desc, device_ids, nx, ny, ns, max_depth=25, **kw):
+    """The whole frame traced by several GPUs of this process (tile shards added on the host)."""
+    p = make_params(nx, ny, ns, max_depth, **kw)
+    ids = (C.c_int32 * len(device_ids))(*device_ids)
+    out = np.zeros((ny, nx, 3), np.float32)
+    _check(library().pt_render_on_devices(desc.ptr, C.byref(p), ids, len(device_ids), out.ctypes.data))
+    return out
 
 
 def frame_finish(d_frame_ptr, n_floats, total_samples, stream=None):

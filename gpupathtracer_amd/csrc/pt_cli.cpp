@@ -107,7 +107,7 @@ int main(int argc, char** argv)
     if (gpus > have) { std::cerr << "--gpus " << gpus << " but only " << have << " device(s) visible" << std::endl; return EXIT_FAILURE; }
 
     PtRenderParams p{};
-    p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = maxDepth; p.shard_count = gpus; p.tile_w = 8; p.tile_h = 8;
+    p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = maxDepth; p.tile_w = 8; p.tile_h = 8;
     p.pipeline = (pipeline == "wavefront") ? PT_PIPELINE_WAVEFRONT : PT_PIPELINE_FUSED;
 
     if (passSamples > 0 && gpus == 1) {          // one device, progress after every pass
@@ -136,32 +136,16 @@ int main(int argc, char** argv)
     }
     if (passSamples > 0) std::cerr << "--pass-samples applies to one GPU; rendering in one pass per device." << std::endl;
 
-    std::cerr << "Allocating world...";
-    std::vector<PtScene*> scenes((size_t)gpus, nullptr);
-    std::vector<void*> frames((size_t)gpus, nullptr);
+    std::cerr << "Allocating and rendering world...";
     const size_t n_floats = (size_t)3 * nx * ny;
-    for (int g = 0; g < gpus; g++) {
-        if (pt_set_device(g) != PT_OK) return fail("set device");
-        if (pt_scene_create(desc, &scenes[(size_t)g]) != PT_OK) return fail("\nFailed to allocate world in GPU memory");
-        if (pt_device_malloc(n_floats * sizeof(float), &frames[(size_t)g]) != PT_OK) return fail("frame buffer");
-    }
-    std::cerr << "done" << std::endl << "Rendering world...";
+    std::vector<float> image(n_floats, 0.0f);
+    std::vector<int32_t> ids((size_t)gpus);
+    for (int g = 0; g < gpus; g++) ids[(size_t)g] = g;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int g = 0; g < gpus; g++) {             // every device traces its tile shard concurrently
-        if (pt_set_device(g) != PT_OK) return fail("set device");
-        p.shard_index = g;
-        if (pt_render_device(scenes[(size_t)g], &p, frames[(size_t)g], nullptr) != PT_OK) return fail("\nFailed to render on GPU");
-    }
-    std::vector<float> image(n_floats, 0.0f), part(n_floats);
-    for (int g = 0; g < gpus; g++) {
-        if (pt_set_device(g) != PT_OK || pt_device_synchronize() != PT_OK) return fail("\nFailed to render on GPU");
-        if (pt_memcpy_to_host(part.data(), frames[(size_t)g], n_floats * sizeof(float)) != PT_OK) return fail("copy back");
-        for (size_t i = 0; i < n_floats; i++) image[i] += part[i];    // shards are disjoint: x + 0 = x
-    }
+    if (pt_render_on_devices(desc, &p, ids.data(), gpus, image.data()) != PT_OK) return fail("\nFailed to render on GPU");
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "done" << std::endl;
-    std::cerr << (double)nx * ny * ns / sec / 1e6 << " Mpaths/s (" << sec << " s, " << gpus << " GPU)" << std::endl;
-    for (int g = 0; g < gpus; g++) { pt_set_device(g); pt_device_free(frames[(size_t)g]); pt_scene_destroy(scenes[(size_t)g]); }
+    std::cerr << (double)nx * ny * ns / sec / 1e6 << " Mpaths/s including scene upload (" << sec << " s, " << gpus << " GPU)" << std::endl;
     pt_scene_desc_free(desc);
     if (median) {                                // medianFilter3x3 before writeImage, src/ptMain.cu:684-689
         std::vector<float> filtered(n_floats);

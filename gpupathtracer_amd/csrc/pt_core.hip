@@ -678,6 +678,49 @@ extern "C" int pt_render(PtScene* sc, const PtRenderParams* p, float* out_rgb)
     return rc;
 }
 
+extern "C" int pt_render_on_devices(const PtSceneDesc* desc, const PtRenderParams* p, const int32_t* device_ids, int32_t n_devices,
+                                    float* out_rgb)
+{
+    if (!desc || !p || !out_rgb || !device_ids || n_devices <= 0) { pt::set_error("pt_render_on_devices: bad arguments"); return PT_ERR_INVALID; }
+    if (p->nx <= 0 || p->ny <= 0) { pt::set_error("render: nx, ny must be positive"); return PT_ERR_INVALID; }
+    if (p->shard_count > 1 || p->batch_count > 1) { pt::set_error("pt_render_on_devices: the call shards by itself"); return PT_ERR_INVALID; }
+    int previous = 0;
+    (void)hipGetDevice(&previous);
+    const size_t n_floats = (size_t)3 * p->nx * p->ny;
+    std::vector<PtScene*> scenes((size_t)n_devices, nullptr);
+    std::vector<void*> frames((size_t)n_devices, nullptr);
+    int rc = PT_OK;
+    for (int g = 0; g < n_devices && rc == PT_OK; g++) {          // scene replicated on every device
+        if (!hip_ok(hipSetDevice(device_ids[g]), "hipSetDevice")) { rc = PT_ERR_HIP; break; }
+        rc = pt_scene_create(desc, &scenes[(size_t)g]);
+        if (rc == PT_OK && !hip_ok(hipMalloc(&frames[(size_t)g], n_floats * sizeof(float)), "hipMalloc(frame)")) rc = PT_ERR_OOM;
+    }
+    PtRenderParams q = *p;
+    q.shard_count = n_devices;
+    if (q.tile_w <= 0) q.tile_w = 8;
+    if (q.tile_h <= 0) q.tile_h = 8;
+    for (int g = 0; g < n_devices && rc == PT_OK; g++) {          // launches return at once: the devices trace concurrently
+        if (!hip_ok(hipSetDevice(device_ids[g]), "hipSetDevice")) { rc = PT_ERR_HIP; break; }
+        q.shard_index = g;
+        rc = pt_render_device(scenes[(size_t)g], &q, frames[(size_t)g], nullptr);
+    }
+    std::vector<float> part(rc == PT_OK ? n_floats : 0);
+    if (rc == PT_OK) std::fill(out_rgb, out_rgb + n_floats, 0.0f);
+    for (int g = 0; g < n_devices && rc == PT_OK; g++) {
+        if (!hip_ok(hipSetDevice(device_ids[g]), "hipSetDevice") || !hip_ok(hipDeviceSynchronize(), "render (synchronize)") ||
+            !hip_ok(hipMemcpy(part.data(), frames[(size_t)g], n_floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(frame)")) { rc = PT_ERR_HIP; break; }
+        for (size_t i = 0; i < n_floats; i++) out_rgb[i] += part[i];      // shards are disjoint and zero elsewhere: x + 0 = x
+    }
+    for (int g = 0; g < n_devices; g++) {
+        if (!scenes[(size_t)g] && !frames[(size_t)g]) continue;
+        (void)hipSetDevice(device_ids[g]);
+        if (frames[(size_t)g]) (void)hipFree(frames[(size_t)g]);
+        pt_scene_destroy(scenes[(size_t)g]);
+    }
+    (void)hipSetDevice(previous);
+    return rc;
+}
+
 extern "C" int pt_render_stats(PtScene* sc, PtRenderStats* stats)
 {
     if (!sc || !stats) { pt::set_error("pt_render_stats: null argument"); return PT_ERR_INVALID; }

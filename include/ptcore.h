@@ -246,6 +246,14 @@ int  pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, int32_t* prim
 /* Fills *stats with the timings of the scene's most recent render call; waits for it. */
 int  pt_render_stats(PtScene* scene, PtRenderStats* stats);
 
+/* One call, several GPUs of this process: the scene is created on every device of device_ids,
+ * each traces the 8x8-tile shard (shard_index = its position in device_ids) concurrently, and the
+ * shards are added on the host; the image is the one-device image bit for bit.  The call a
+ * single-process host like the reference's main() (src/ptMain.cu:579-653, one device) makes
+ * instead of running one process per GPU.  params->shard_* and batch_* must be unset. */
+int  pt_render_on_devices(const PtSceneDesc* desc, const PtRenderParams* params, const int32_t* device_ids,
+                          int32_t n_devices, float* out_rgb);
+
 /* frame[i] = sqrt(max(0, frame[i] * (1 / total_samples))) over n_floats device floats: the
  * averaging and gamma of render_pixel (src/ptMain.cu:163-166) for a frame of raw sums. */
 int  pt_frame_finish_device(void* d_frame, size_t n_floats, int32_t total_samples, void* hip_stream);

@@ -390,3 +390,16 @@ def test_sample_batches_are_a_labelled_departure(oracle):
         sc.render(nx, ny, 4, batch_index=4, batch_count=4)
     with pytest.raises(pt.PtError):
         sc.render(nx, ny, 4, batch_index=1, batch_count=2, pipeline=abi.PIPELINE_WAVEFRONT)
+
+
+def test_render_on_devices_adds_up_to_the_one_device_image(oracle):
+    """One call, several device slots (the same GPU named three times on a one-GPU box): scene created
+    per slot, tile shards traced and added on the host, image bit-identical to the oracle's."""
+    d = pt.builtin_scene("cornell", 100 / 60)
+    ref = oracle.render(d, 100, 60, 4)
+    assert_bit_exact(pt.render_on_devices(d, [0, 0, 0], 100, 60, 4), ref, "three slots on device 0")
+    assert_bit_exact(pt.render_on_devices(d, [0], 100, 60, 4), ref, "one slot")
+    with pytest.raises(pt.PtError):
+        pt.render_on_devices(d, [0, 0], 100, 60, 4, shard_index=0, shard_count=2)
+    with pytest.raises(pt.PtError):
+        pt.render_on_devices(d, [99], 100, 60, 4)
