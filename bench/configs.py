@@ -31,7 +31,7 @@ def run(label, desc, nx, ny, spp, steps=2, **kw):
     k = min(ms)
     out = {"config": label, "nx": nx, "ny": ny, "spp": spp, "kernel_ms": k, "Mpaths_per_s": nx * ny * spp / k / 1e3,
            "scene_create_s": create_s, "lbvh_nodes": int(pt.library().pt_scene_lbvh_nodes(sc._h, None, 0)),
-           "schedule": st.schedule, "shapes": desc.c.n_shapes, "world": desc.c.n_world}
+           "schedule": st.schedule, "pipeline": st.pipeline, "launches": st.n_launches, "shapes": desc.c.n_shapes, "world": desc.c.n_world}
     print(json.dumps(out), flush=True)
     return out
 
@@ -41,20 +41,22 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--grid", type=int, default=1000, help="height-field resolution (1000 -> 2 000 000 triangles)")
     ap.add_argument("--only", default="")
+    ap.add_argument("--pipeline", choices=("fused", "wavefront"), default="fused")
     a = ap.parse_args()
     q = 16 if a.quick else 1
     pt.set_device(0)
+    kw = {"pipeline": abi.PIPELINE_WAVEFRONT} if a.pipeline == "wavefront" else {}
     res = []
     if a.only in ("", "c1"):
-        res.append(run("C1 random_scene 1920x1080 LBVH", pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 1024 // q))
+        res.append(run("C1 random_scene 1920x1080 LBVH", pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 1024 // q, **kw))
     if a.only in ("", "c1list"):
-        res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1))
+        res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1, **kw))
     if a.only in ("", "c3"):
-        res.append(run("C3 final 1920x1080", pt.builtin_scene("final", 16 / 9), 1920, 1080, 256 // q))
+        res.append(run("C3 final 1920x1080", pt.builtin_scene("final", 16 / 9), 1920, 1080, 256 // q, **kw))
     if a.only in ("", "c4"):
         d = pt.trimesh_scene(a.grid, 16 / 9)
         d.c.accel = abi.ACCEL_LBVH
-        res.append(run("C4 height field %d triangles in the Cornell enclosure 3840x2160 LBVH" % (2 * a.grid * a.grid), d, 3840, 2160, 64 // q, steps=1))
+        res.append(run("C4 height field %d triangles in the Cornell enclosure 3840x2160 LBVH" % (2 * a.grid * a.grid), d, 3840, 2160, 64 // q, steps=1, **kw))
     return res
 
 
