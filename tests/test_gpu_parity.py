@@ -403,3 +403,12 @@ def test_render_on_devices_adds_up_to_the_one_device_image(oracle):
         pt.render_on_devices(d, [0, 0], 100, 60, 4, shard_index=0, shard_count=2)
     with pytest.raises(pt.PtError):
         pt.render_on_devices(d, [99], 100, 60, 4)
+
+
+def test_wavefront_scheduler_over_the_lbvh(oracle):
+    """The staged scheduler with the library-built tree: spheres (distance pruning) and triangles (none)."""
+    d = pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)
+    assert_bit_exact(pt.Scene(d).render(80, 40, 4, pipeline=abi.PIPELINE_WAVEFRONT), oracle.render(d, 80, 40, 4), "random, LBVH, staged")
+    t = pt.trimesh_scene(24, 1.5)
+    t.c.accel = abi.ACCEL_LBVH
+    assert_bit_exact(pt.Scene(t).render(60, 40, 4, pipeline=abi.PIPELINE_WAVEFRONT), oracle.render(t, 60, 40, 4), "trimesh, LBVH, staged")
