@@ -316,7 +316,9 @@ bool fail(const char* msg) { pt::set_error(msg); return false; }
 bool validate(const PtSceneDesc* d, uint32_t* mask_out)
 {
     uint32_t mask = 0;
-    if (d->n_shapes < 0 || d->n_world <= 0 || d->n_materials < 0 || d->n_textures < 0) return fail("scene: negative or empty counts");
+    if (d->n_shapes < 0 || d->n_world <= 0 || d->n_materials < 0 || d->n_textures < 0 || d->n_tri_uvs < 0 || d->n_xforms < 0 ||
+        d->n_texels < 0 || d->n_media < 0 || d->n_bvh_nodes < 0 || d->n_bvhs < 0 || d->n_lights < 0)
+        return fail("scene: negative or empty counts");
     if ((d->n_shapes && !d->shapes) || !d->world || (d->n_materials && !d->materials) || (d->n_textures && !d->textures))
         return fail("scene: null array with non-zero count");
     if ((d->n_xforms && !d->xforms) || (d->n_media && !d->media) || (d->n_bvh_nodes && !d->bvh_nodes) || (d->n_bvhs && !d->bvhs) ||

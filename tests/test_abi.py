@@ -81,3 +81,44 @@ def test_libm_host_build_matches_glibc(oracle):
         b = oracle.libm(fn, arg)
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (fn, arg[~same][:5])
+
+
+def test_corrupted_descriptions_are_refused_not_executed():
+    """Every integer field a kernel would index with, damaged one at a time in every scene: scene
+    creation must answer PT_ERR_INVALID (or accept a still-sound description), never fault."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    lib = pt.library()
+    bad_values = (-7, -2, 10_000_000, 2_000_000_000)
+    refused = accepted = 0
+    for name, aspect in (("cornell", 1.0), ("final", 1.5), ("simple_light", 2.0), ("random", 2.0)):
+        d = pt.builtin_scene(name, aspect)
+        c = d.c
+        targets = []
+        for arr, n, fields in ((c.shapes, c.n_shapes, ("type", "material", "xform_first", "xform_count", "tri_uv")),
+                               (c.materials, c.n_materials, ("type", "texture")), (c.textures, c.n_textures, ("type", "odd", "even")),
+                               (c.world, c.n_world, ("type", "index")), (c.media, c.n_media, ("boundary", "material")),
+                               (c.bvh_nodes, c.n_bvh_nodes, ("left", "right")), (c.bvhs, c.n_bvhs, ("root", "xform_first", "xform_count")),
+                               (c.xforms, c.n_xforms, ("type",))):
+            for i in (rng.choice(n, size=min(n, 6), replace=False) if n else ()):
+                for f in fields:
+                    targets.append((arr, int(i), f))
+        for arr, i, f in targets:
+            keep = getattr(arr[i], f)
+            for v in bad_values:
+                setattr(arr[i], f, v)
+                h = C.c_void_p()
+                rc = lib.pt_scene_create(d.ptr, C.byref(h))
+                assert rc in (abi.OK, abi.ERR_INVALID, abi.ERR_NO_DEVICE, abi.ERR_UNSUPPORTED), (name, f, v, rc)
+                if rc == abi.OK:
+                    lib.pt_scene_destroy(h)
+                refused += rc == abi.ERR_INVALID
+                accepted += rc != abi.ERR_INVALID
+            setattr(arr[i], f, keep)
+        for cnt in ("n_shapes", "n_xforms", "n_media", "n_lights", "n_world", "n_bvh_nodes"):
+            keep = getattr(c, cnt)
+            setattr(c, cnt, -3)
+            h = C.c_void_p()
+            assert lib.pt_scene_create(d.ptr, C.byref(h)) == abi.ERR_INVALID, cnt
+            setattr(c, cnt, keep)
+    assert refused > 500
