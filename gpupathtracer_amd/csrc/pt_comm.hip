@@ -14,6 +14,7 @@ int hip_err(hipError_t e, const char* what)
 {
     std::string msg = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     pt::set_error(msg.c_str());
+    (void)hipGetLastError();      // the runtime keeps the last error until it is read: do not let it surface in a later call
     return PT_ERR_HIP;
 }
 int nccl_err(ncclResult_t r, const char* what)

@@ -25,6 +25,16 @@ using namespace ptk;
 
 // ---- kernels ----------------------------------------------------------------------------------------
 
+// Workgroups per CU the fused kernels are compiled for (a register cap).  The compiler's free choice
+// leaves the rectangle-scene kernel at 5 waves per SIMD and the full-feature kernels at 2; the
+// values below measured fastest on MI355X: Cornell 1024^2 124.5 -> 118.9 ms at 6 (7: 122.2, 8: 125.6,
+// spills), final scene 54.4 -> 40.5 ms at 4 (3: 43.3, 6: 40.9), 2M-triangle field 40.7 -> 33.1 ms at 6
+// (the LDS traversal stack allows six workgroups per CU; 8 with a shorter stack measured the same).
+__host__ __device__ constexpr int fused_min_blocks(uint32_t F)
+{
+    return (F & F_REFBVH) ? 4 : (F == M_CORNELL) ? 6 : (F == M_TRIMESH) ? 6 : 1;
+}
+
 // One lane's path tracer state: the pixel's random stream, its running sum and the path in flight.
 struct LaneState {
     Pcg rng;
@@ -107,7 +117,7 @@ __device__ __forceinline__ void lane_init(LaneState& st)
 // Fused scheduler, one 8x8 tile per wave and one pixel per lane.  The lanes of a wave start in
 // phase, which keeps the shading branches less divergent when shading dominates a bounce.
 template <uint32_t F>
-__global__ __launch_bounds__(256) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
+__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const int lane = threadIdx.x & 63;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256) void k_render_tiles(SceneView sv, RenderArgs r
 // writes the estimate so far, sqrt(sum / samples done), the reference's normalisation
 // (src/ptMain.cu:163-166) applied to the samples that exist.
 template <uint32_t F>
-__global__ __launch_bounds__(256) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
+__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
                                                      int first, float* __restrict__ out)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void k_render_pass(SceneView sv, RenderArgs ra
 // uniform over the wave, dominates a bounce.  Which lane traces a pixel does not matter: the
 // pixel's random stream is seeded by its index (src/ptMain.cu:178-184).
 template <uint32_t F>
-__global__ __launch_bounds__(256) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
+__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
                                                        unsigned* __restrict__ next_slot)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
@@ -293,6 +303,7 @@ bool hip_ok(hipError_t e, const char* what)
     if (e == hipSuccess) return true;
     std::string msg = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     pt::set_error(msg.c_str());
+    (void)hipGetLastError();      // the runtime keeps the last error until it is read: do not let it surface in a later call
     return false;
 }
 

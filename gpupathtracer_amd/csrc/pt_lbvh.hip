@@ -235,6 +235,7 @@ int hip_fail(hipError_t e, const char* what)
 {
     std::string msg = std::string("lbvh_build: ") + what + ": " + hipGetErrorName(e);
     pt::set_error(msg.c_str());
+    (void)hipGetLastError();      // the runtime keeps the last error until it is read: do not let it surface in a later call
     return PT_ERR_HIP;
 }
 

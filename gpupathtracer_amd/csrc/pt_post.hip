@@ -52,6 +52,7 @@ bool hip_ok(hipError_t e, const char* what)
 {
     if (e == hipSuccess) return true;
     pt::set_error((std::string(what) + ": " + hipGetErrorString(e)).c_str());
+    (void)hipGetLastError();      // the runtime keeps the last error until it is read: do not let it surface in a later call
     return false;
 }
 

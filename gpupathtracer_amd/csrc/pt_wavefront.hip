@@ -273,6 +273,7 @@ bool hip_ok2(hipError_t e, const char* what)
     if (e == hipSuccess) return true;
     std::string msg = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
     pt::set_error(msg.c_str());
+    (void)hipGetLastError();      // the runtime keeps the last error until it is read: do not let it surface in a later call
     return false;
 }
 
