@@ -288,7 +288,7 @@ class Scene:
     def __init__(self, desc):
         lib = library()
         h = C.c_void_p()
-        ptr = desc.ptr if isinstance(desc, SceneDesc) else desc
+        ptr = desc.ptr if hasattr(desc, "ptr") else desc
         _check(lib.pt_scene_create(ptr, C.byref(h)))
         self._h = h
 

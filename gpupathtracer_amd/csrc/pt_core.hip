@@ -417,12 +417,16 @@ bool validate(const PtSceneDesc* d, uint32_t* mask_out)
         else return fail("world: unknown object type");
     }
     if (d->n_lights < 0) return fail("lights: negative count");
-    if (d->n_lights > 0) {
+    if (d->lights_is_list < 0 || d->lights_is_list > 2) return fail("lights: lights_is_list must be 0, 1 or 2");
+    if (d->n_lights > 0 && d->lights_is_list == 2) {     // a BVH of light shapes
+        if (d->n_lights != 1 || d->lights[0] < 0 || d->lights[0] >= d->n_bvhs) return fail("lights: bvh out of range");
+        mask |= F_LIGHTS | F_LIGHT_MISC | F_REFBVH;
+    } else if (d->n_lights > 0) {
         mask |= F_LIGHTS;
         for (int i = 0; i < d->n_lights; i++)
             if (d->lights[i] < 0 || d->lights[i] >= d->n_shapes) return fail("lights: shape out of range");
         const PtShape& l0 = d->shapes[d->lights[0]];
-        if (d->lights_is_list || d->n_lights > 1 || l0.type != PT_SHAPE_RECT_XZ || l0.xform_count != 0) mask |= F_LIGHT_MISC;
+        if (d->lights_is_list || d->n_lights > 1 || l0.type != PT_SHAPE_RECT_XZ || l0.xform_count != 0 || (l0.flags & PT_FLIP_NORMAL)) mask |= F_LIGHT_MISC;
         if (!d->lights_is_list && d->n_lights != 1) return fail("lights: more than one light shape needs lights_is_list");
     }
     if (d->ambient_type == PT_AMBIENT_SKY) mask |= F_SKY;

@@ -826,6 +826,7 @@ __device__ __forceinline__ float light_shape_pdf(const SceneView& sv, int shape,
 {
     const PtShape* s = &sv.shapes[shape];
     Ray r; r.o = o; r.d = v; r.time = 0;
+    if ((F & F_LIGHT_MISC) && (s->flags & PT_FLIP_NORMAL)) return 0;                       // FlipNormals has no pdfValue of its own
     if (!(F & F_LIGHT_MISC) || (s->type == PT_SHAPE_RECT_XZ && s->xform_count == 0)) {   // include/ptRectangle.h:77-89
         float t;
         if (rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], 0.001f, FLT_MAX, t)) {
@@ -852,6 +853,7 @@ template <uint32_t F>
 __device__ __forceinline__ V3 light_shape_random(const SceneView& sv, int shape, V3 o, Pcg& g)
 {
     const PtShape* s = &sv.shapes[shape];
+    if ((F & F_LIGHT_MISC) && (s->flags & PT_FLIP_NORMAL)) return mk(1, 0, 0);            // FlipNormals has no random() of its own
     if (!(F & F_LIGHT_MISC) || (s->type == PT_SHAPE_RECT_XZ && s->xform_count == 0)) {   // include/ptRectangle.h:91-95
         float rz = g.rand();       // g++ evaluates the constructor arguments right to left
         float rx = g.rand();
@@ -866,9 +868,55 @@ __device__ __forceinline__ V3 light_shape_random(const SceneView& sv, int shape,
     }
     return mk(1, 0, 0);                                                                    // include/ptHitable.h:59
 }
+// BVH::pdfValue (src/ptBVH.cu:82-87): 0.5f * left + 0.5f * right at every node, evaluated in the
+// recursion's order with an explicit stack (phase 0: left pending, 1: right pending, 2: combine).
+template <uint32_t F>
+__device__ inline float light_tree_pdf(const SceneView& sv, int bvh_index, V3 o, V3 v)
+{
+    const PtBvh b = sv.bvhs[bvh_index];
+    if (b.xform_count > 0) return 0;                      // Translate / RotateY do not forward pdfValue
+    int node[REFBVH_STACK], phase[REFBVH_STACK];
+    float left[REFBVH_STACK];
+    int sp = 1;
+    node[0] = b.root; phase[0] = 0; left[0] = 0;
+    float ret = 0;
+    while (sp > 0) {
+        const int e = sp - 1;
+        const PtBvhNode* n = &sv.bvh_nodes[node[e]];
+        if (phase[e] == 0) {
+            phase[e] = 1;
+            if (n->left >= 0) { if (sp < REFBVH_STACK) { node[sp] = n->left; phase[sp] = 0; left[sp] = 0; sp++; continue; } ret = 0; }
+            else ret = light_shape_pdf<F>(sv, ~n->left, o, v);
+        }
+        if (phase[e] == 1) {
+            left[e] = ret; phase[e] = 2;
+            if (n->right >= 0) { if (sp < REFBVH_STACK) { node[sp] = n->right; phase[sp] = 0; left[sp] = 0; sp++; continue; } ret = 0; }
+            else ret = light_shape_pdf<F>(sv, ~n->right, o, v);
+        }
+        const float weight = 0.5f;
+        ret = weight * left[e] + weight * ret;
+        sp--;
+    }
+    return ret;
+}
+// BVH::random (src/ptBVH.cu:89-95)
+template <uint32_t F>
+__device__ inline V3 light_tree_random(const SceneView& sv, int bvh_index, V3 o, Pcg& g)
+{
+    const PtBvh b = sv.bvhs[bvh_index];
+    if (b.xform_count > 0) return mk(1, 0, 0);
+    int cur = b.root;
+    while (cur >= 0) {
+        const PtBvhNode* n = &sv.bvh_nodes[cur];
+        cur = (g.rand() < 0.5f) ? n->left : n->right;
+    }
+    return light_shape_random<F>(sv, ~cur, o, g);
+}
+
 template <uint32_t F>
 __device__ __forceinline__ float lights_pdf(const SceneView& sv, V3 o, V3 v)
 {
+    if ((F & F_LIGHT_MISC) && (F & F_REFBVH) && sv.lights_is_list == 2) return light_tree_pdf<F>(sv, sv.lights[0], o, v);
     if (!(F & F_LIGHT_MISC) || !sv.lights_is_list) return light_shape_pdf<F>(sv, sv.lights[0], o, v);
     float weight = 1 / (float)sv.n_lights;                                                 // include/ptHitableList.h:29-38
     float sum = 0;
@@ -878,6 +926,7 @@ __device__ __forceinline__ float lights_pdf(const SceneView& sv, V3 o, V3 v)
 template <uint32_t F>
 __device__ __forceinline__ V3 lights_random(const SceneView& sv, V3 o, Pcg& g)
 {
+    if ((F & F_LIGHT_MISC) && (F & F_REFBVH) && sv.lights_is_list == 2) return light_tree_random<F>(sv, sv.lights[0], o, g);
     if (!(F & F_LIGHT_MISC) || !sv.lights_is_list) return light_shape_random<F>(sv, sv.lights[0], o, g);
     int index = (int)(g.rand() * sv.n_lights);                                             // include/ptHitableList.h:40-44
     return light_shape_random<F>(sv, sv.lights[index], o, g);

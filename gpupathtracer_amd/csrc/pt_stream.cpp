@@ -498,6 +498,7 @@ extern "C" int pt_scene_desc_to_stream(const PtSceneDesc* d, void* buffer, size_
             }
         }
         mark[1] = w.off;
+        if (d->n_lights > 0 && d->lights_is_list == 2) throw Fail{ "light shapes in a BVH are not supported by the reference's stream format" };
         if (d->n_lights <= 0) w.i32(ID_NULL);
         else if (!d->lights_is_list) w.shape(d->lights[0]);
         else {

@@ -155,9 +155,16 @@ typedef struct PtSceneDesc {
     int32_t n_bvh_nodes;  const PtBvhNode*  bvh_nodes;
     int32_t n_bvhs;       const PtBvh*      bvhs;
     int32_t n_world;      const PtObject*   world;       /* ordered top-level list */
-    /* lightShapes argument of color() (src/ptMain.cu:95,119-127): shape indices.
-     * lights_is_list != 0 reproduces a HitableList of lights (uniform mixture,
-     * one extra RNG draw per sample, include/ptHitableList.h:29-44). */
+    /* lightShapes argument of color() (src/ptMain.cu:95,119-127).
+     * lights_is_list == 0: lights[0] is the one light shape (shape index).
+     * lights_is_list == 1: a HitableList of light shapes (uniform mixture, one extra RNG draw per
+     *                      sample, include/ptHitableList.h:29-44); lights[] are shape indices.
+     * lights_is_list == 2: a BVH of light shapes: lights[0] is an index into bvhs; pdfValue is
+     *                      0.5 * left + 0.5 * right at every node, random() descends on
+     *                      rand() < 0.5 (src/ptBVH.cu:82-95).
+     * Only an un-wrapped XZ rectangle or sphere has a pdf of its own; any other light shape,
+     * and any shape under FlipNormals / Translate / RotateY, answers like the Hitable base class:
+     * pdfValue 0, random (1,0,0) (include/ptHitable.h:58-59). */
     int32_t n_lights;     const int32_t*    lights;
     int32_t lights_is_list;
     int32_t ambient_type; /* PtAmbientType */

@@ -669,6 +669,7 @@ static float light_shape_pdf(const PtSceneDesc* sc, int shape, v3 o, v3 v, pcg_t
     ray_t r; r.o = o; r.d = v; r.time = 0;
     hitrec rec;
     memset(&rec, 0, sizeof rec);
+    if (s->flags & PT_FLIP_NORMAL) return 0;                                              /* FlipNormals: ptHitable.h:58 */
     if (s->xform_count == 0 && s->type == PT_SHAPE_RECT_XZ) {                             /* ptRectangle.h:77-89 */
         if (rect_hit(1, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], s->material, &r, 0.001f, FLT_MAX, &rec)) {
             FL(8);
@@ -696,6 +697,7 @@ static float light_shape_pdf(const PtSceneDesc* sc, int shape, v3 o, v3 v, pcg_t
 static v3 light_shape_random(const PtSceneDesc* sc, int shape, v3 o, pcg_t* rng)
 {
     const PtShape* s = &sc->shapes[shape];
+    if (s->flags & PT_FLIP_NORMAL) return V(1, 0, 0);                                     /* FlipNormals: ptHitable.h:59 */
     if (s->xform_count == 0 && s->type == PT_SHAPE_RECT_XZ) {                             /* ptRectangle.h:91-95 */
         /* g++ evaluates the constructor arguments right to left: z is drawn before x */
         float rz = pcg_rand(rng);
@@ -714,8 +716,32 @@ static v3 light_shape_random(const PtSceneDesc* sc, int shape, v3 o, pcg_t* rng)
     }
     return V(1, 0, 0);                                                                    /* ptHitable.h:59 */
 }
+/* BVH::pdfValue / BVH::random (src/ptBVH.cu:82-95) */
+static float light_tree_pdf(const PtSceneDesc* sc, int child, v3 o, v3 v, pcg_t* rng)
+{
+    if (child < 0) return light_shape_pdf(sc, ~child, o, v, rng);
+    const PtBvhNode* n = &sc->bvh_nodes[child];
+    float weight = 0.5f;
+    FL(3);
+    float sum = weight * light_tree_pdf(sc, n->left, o, v, rng) + weight * light_tree_pdf(sc, n->right, o, v, rng);
+    return sum;
+}
+static v3 light_tree_random(const PtSceneDesc* sc, int child, v3 o, pcg_t* rng)
+{
+    if (child < 0) return light_shape_random(sc, ~child, o, rng);
+    const PtBvhNode* n = &sc->bvh_nodes[child];
+    FL(1);
+    if (pcg_rand(rng) < 0.5f) return light_tree_random(sc, n->left, o, rng);
+    return light_tree_random(sc, n->right, o, rng);
+}
+
 static float lights_pdf(const PtSceneDesc* sc, v3 o, v3 v, pcg_t* rng)
 {
+    if (sc->lights_is_list == 2) {
+        const PtBvh* b = &sc->bvhs[sc->lights[0]];
+        if (b->xform_count > 0) return 0;                                                 /* ptHitable.h:58 */
+        return light_tree_pdf(sc, b->root, o, v, rng);
+    }
     if (!sc->lights_is_list) return light_shape_pdf(sc, sc->lights[0], o, v, rng);
     FL(1 + 2 * sc->n_lights);
     float weight = 1 / (float)sc->n_lights;                                               /* ptHitableList.h:29-38 */
@@ -725,6 +751,11 @@ static float lights_pdf(const PtSceneDesc* sc, v3 o, v3 v, pcg_t* rng)
 }
 static v3 lights_random(const PtSceneDesc* sc, v3 o, pcg_t* rng)
 {
+    if (sc->lights_is_list == 2) {
+        const PtBvh* b = &sc->bvhs[sc->lights[0]];
+        if (b->xform_count > 0) return V(1, 0, 0);                                        /* ptHitable.h:59 */
+        return light_tree_random(sc, b->root, o, rng);
+    }
     if (!sc->lights_is_list) return light_shape_random(sc, sc->lights[0], o, rng);
     FL(1);
     int index = (int)(pcg_rand(rng) * sc->n_lights);                                      /* ptHitableList.h:40-44 */

@@ -412,3 +412,48 @@ def test_wavefront_scheduler_over_the_lbvh(oracle):
     t = pt.trimesh_scene(24, 1.5)
     t.c.accel = abi.ACCEL_LBVH
     assert_bit_exact(pt.Scene(t).render(60, 40, 4, pipeline=abi.PIPELINE_WAVEFRONT), oracle.render(t, 60, 40, 4), "trimesh, LBVH, staged")
+
+
+def light_tree_scene():
+    """Cornell box lit through a BVH of light shapes: ((left half of the lamp, right half), a sphere light)."""
+    from tests._desc_tools import OwnedDesc
+    from gpupathtracer_amd import _abi as A
+    d = OwnedDesc(pt.builtin_scene("cornell", 1.0))
+    lamp_mat = d.lists["shapes"][2].material
+    def xz(x0, x1):
+        s = A.PtShape(type=abi.SHAPE_RECT_XZ, flags=0, material=lamp_mat, xform_first=0, xform_count=0, tri_uv=-1)
+        for k, v in enumerate((x0, x1, 227.0, 332.0, 554.0)):
+            s.p[k] = v
+        return s
+    ball = A.PtShape(type=abi.SHAPE_SPHERE, flags=0, material=lamp_mat, xform_first=0, xform_count=0, tri_uv=-1)
+    for k, v in enumerate((400.0, 400.0, 300.0, 40.0)):
+        ball.p[k] = v
+    flipped = xz(213.0, 343.0)
+    flipped.flags = abi.FLIP_NORMAL                      # answers like the Hitable base class
+    base = len(d.lists["shapes"])
+    d.lists["shapes"] += [xz(213.0, 278.0), xz(278.0, 343.0), ball, flipped]
+    n0 = A.PtBvhNode(left=~base, right=~(base + 1))
+    n1 = A.PtBvhNode(left=0, right=~(base + 2))
+    n2 = A.PtBvhNode(left=1, right=~(base + 3))
+    d.lists["bvh_nodes"] = [n0, n1, n2]
+    d.lists["bvhs"] = [A.PtBvh(root=2, xform_first=0, xform_count=0)]
+    d.lists["world"].append(A.PtObject(type=abi.OBJ_SHAPE, index=base + 2))      # the sphere light is visible too
+    d.lists["lights"] = [0]
+    d.scalars["lights_is_list"] = 2
+    return d.finalize()
+
+
+def test_light_shapes_in_a_bvh(oracle):
+    """BVH::pdfValue / BVH::random (src/ptBVH.cu:82-95) as the lightShapes argument: no reference scene
+    does this, the oracle restates the recursion.  Parity unpinned."""
+    d = light_tree_scene()
+    sc = pt.Scene(d)
+    ref = oracle.render(d, 72, 72, 8)
+    assert_bit_exact(sc.render(72, 72, 8), ref, "light tree, fused")
+    assert_bit_exact(sc.render(72, 72, 8, schedule=abi.SCHEDULE_TILES), ref, "light tree, tiles")
+    assert_bit_exact(sc.render(72, 72, 8, pipeline=abi.PIPELINE_WAVEFRONT), ref, "light tree, staged")
+    plain = oracle.render(pt.builtin_scene("cornell", 1.0), 72, 72, 8)
+    assert not np.array_equal(ref, plain)
+    d.c.lights[0] = 5
+    with pytest.raises(pt.PtError):
+        pt.Scene(d)
