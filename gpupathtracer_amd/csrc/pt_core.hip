@@ -57,7 +57,7 @@ __device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs
 }
 
 // One bounce of the pixel's sample loop.  Returns true when the pixel's last sample has ended.
-template <uint32_t F>
+template <uint32_t F, class W>
 __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, float fnx, float fny,
                                           int* my_stack)
 {
@@ -74,7 +74,7 @@ __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs&
         ended = true;                                     // bounce limit: color() returns the running product
     } else {
         Hit h;
-        if (world_hit<F>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack)) {
+        if (world_hit<F, W>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack)) {
             ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
         } else {
             shade_miss<F>(sv, st.ray, st.thr);
@@ -116,7 +116,7 @@ __device__ __forceinline__ void lane_init(LaneState& st)
 
 // Fused scheduler, one 8x8 tile per wave and one pixel per lane.  The lanes of a wave start in
 // phase, which keeps the shading branches less divergent when shading dominates a bounce.
-template <uint32_t F>
+template <uint32_t F, class W>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(Scene
     lane_init(st);
     unsigned i;
     lane_begin_pixel(st, ra, x, ytop, i);
-    while (!lane_step<F>(sv, ra, st, fnx, fny, my_stack)) {}
+    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {}
     lane_write_pixel(st, ra, i, out);
 }
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(Scene
 // image of a single launch, and lets a host checkpoint `acc` and resume.  Each pass also
 // writes the estimate so far, sqrt(sum / samples done), the reference's normalisation
 // (src/ptMain.cu:163-166) applied to the samples that exist.
-template <uint32_t F>
+template <uint32_t F, class W>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
                                                      int first, float* __restrict__ out)
 {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
         st.accum = mk(a.sum[0], a.sum[1], a.sum[2]);
         st.s = first;
     }
-    while (!lane_step<F>(sv, ra, st, fnx, fny, my_stack)) {}      // ra.ns = first + count for this launch
+    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {}      // ra.ns = first + count for this launch
     PtAccumPixel a;
     a.rng_lo = (uint32_t)st.rng.state; a.rng_hi = (uint32_t)(st.rng.state >> 32);
     a.sum[0] = st.accum.x; a.sum[1] = st.accum.y; a.sum[2] = st.accum.z;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
 // so a wave stays full until the shard runs out.  Pays when the closest-hit search, whose loop is
 // uniform over the wave, dominates a bounce.  Which lane traces a pixel does not matter: the
 // pixel's random stream is seeded by its index (src/ptMain.cu:178-184).
-template <uint32_t F>
+template <uint32_t F, class W>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
                                                        unsigned* __restrict__ next_slot)
 {
@@ -208,14 +208,14 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
             lane_begin_pixel(st, ra, x, ytop, i);
             have = true;
         }
-        if (lane_step<F>(sv, ra, st, fnx, fny, my_stack)) {
+        if (lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {
             lane_write_pixel(st, ra, i, out);
             have = false;
         }
     }
 }
 
-template <uint32_t F>
+template <uint32_t F, class W>
 __global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay* __restrict__ rays, size_t n,
                                                        int32_t* __restrict__ prim_id, float* __restrict__ t_out)
 {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay
     Pcg rng;
     rng.seed(pr.seed);
     Hit h;
-    if (world_hit<F>(sv, r, 0.001f, FLT_MAX, h, rng, my_stack)) { prim_id[i] = h.id; t_out[i] = h.t; }
+    if (world_hit<F, W>(sv, r, 0.001f, FLT_MAX, h, rng, my_stack)) { prim_id[i] = h.id; t_out[i] = h.t; }
     else { prim_id[i] = PT_ID_MISS; t_out[i] = FLT_MAX; }
 }
 
@@ -250,46 +250,74 @@ int pick_variant(uint32_t scene_mask)
     return -1;
 }
 
+// One switch for every launcher: LAUNCH(F, W) is expanded for the variant's feature mask and world walk.
+#define PT_FOR_VARIANT(variant, LAUNCH)                       \
+    switch (variant) {                                        \
+    case 0: LAUNCH(M_CORNELL, AnyWorld); break;               \
+    case 1: LAUNCH(M_SPHERES, AnyWorld); break;               \
+    case 2: LAUNCH(M_SPHERES_LBVH, AnyWorld); break;          \
+    case 3: LAUNCH(M_TRIMESH, AnyWorld); break;               \
+    case 4: LAUNCH(M_ALL, AnyWorld); break;                   \
+    case 5: LAUNCH(M_ALL_LBVH, AnyWorld); break;              \
+    default: LAUNCH(M_CORNELL, CornellWorld); break;          \
+    }
+
 void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
 {
     // REFILL: persistent grid of at most 32 waves per CU, the rest of the shard comes from the counter.
     const bool refill = ra.refill != 0;
     const int tiles4 = (ra.n_wave_tiles + 3) / 4;
     const dim3 block(256), grid(refill ? std::min(tiles4, 2048) : tiles4);
-    switch (variant) {
-    case 0: if (refill) hipLaunchKernelGGL(k_render_refill<M_CORNELL>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_CORNELL>, grid, block, 0, st, sv, ra, out); break;
-    case 1: if (refill) hipLaunchKernelGGL(k_render_refill<M_SPHERES>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_SPHERES>, grid, block, 0, st, sv, ra, out); break;
-    case 2: if (refill) hipLaunchKernelGGL(k_render_refill<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, out); break;
-    case 3: if (refill) hipLaunchKernelGGL(k_render_refill<M_TRIMESH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_TRIMESH>, grid, block, 0, st, sv, ra, out); break;
-    case 4: if (refill) hipLaunchKernelGGL(k_render_refill<M_ALL>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_ALL>, grid, block, 0, st, sv, ra, out); break;
-    default: if (refill) hipLaunchKernelGGL(k_render_refill<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out, next_slot); else hipLaunchKernelGGL(k_render_tiles<M_ALL_LBVH>, grid, block, 0, st, sv, ra, out); break;
-    }
+#define PT_LAUNCH(F, W)                                                                                        \
+    if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot);      \
+    else hipLaunchKernelGGL((k_render_tiles<F, W>), grid, block, 0, st, sv, ra, out)
+    PT_FOR_VARIANT(variant, PT_LAUNCH)
+#undef PT_LAUNCH
 }
 
 void launch_pass(int variant, const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, hipStream_t st)
 {
     const dim3 block(256), grid((ra.n_wave_tiles + 3) / 4);
-    switch (variant) {
-    case 0: hipLaunchKernelGGL(k_render_pass<M_CORNELL>, grid, block, 0, st, sv, ra, acc, first, out); break;
-    case 1: hipLaunchKernelGGL(k_render_pass<M_SPHERES>, grid, block, 0, st, sv, ra, acc, first, out); break;
-    case 2: hipLaunchKernelGGL(k_render_pass<M_SPHERES_LBVH>, grid, block, 0, st, sv, ra, acc, first, out); break;
-    case 3: hipLaunchKernelGGL(k_render_pass<M_TRIMESH>, grid, block, 0, st, sv, ra, acc, first, out); break;
-    case 4: hipLaunchKernelGGL(k_render_pass<M_ALL>, grid, block, 0, st, sv, ra, acc, first, out); break;
-    default: hipLaunchKernelGGL(k_render_pass<M_ALL_LBVH>, grid, block, 0, st, sv, ra, acc, first, out); break;
-    }
+#define PT_LAUNCH(F, W) hipLaunchKernelGGL((k_render_pass<F, W>), grid, block, 0, st, sv, ra, acc, first, out)
+    PT_FOR_VARIANT(variant, PT_LAUNCH)
+#undef PT_LAUNCH
 }
 
 void launch_trace(int variant, const SceneView& sv, const PtRay* rays, size_t n, int32_t* ids, float* ts, hipStream_t st)
 {
     const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    switch (variant) {
-    case 0: hipLaunchKernelGGL(k_trace_closest<M_CORNELL>, grid, block, 0, st, sv, rays, n, ids, ts); break;
-    case 1: hipLaunchKernelGGL(k_trace_closest<M_SPHERES>, grid, block, 0, st, sv, rays, n, ids, ts); break;
-    case 2: hipLaunchKernelGGL(k_trace_closest<M_SPHERES_LBVH>, grid, block, 0, st, sv, rays, n, ids, ts); break;
-    case 3: hipLaunchKernelGGL(k_trace_closest<M_TRIMESH>, grid, block, 0, st, sv, rays, n, ids, ts); break;
-    case 4: hipLaunchKernelGGL(k_trace_closest<M_ALL>, grid, block, 0, st, sv, rays, n, ids, ts); break;
-    default: hipLaunchKernelGGL(k_trace_closest<M_ALL_LBVH>, grid, block, 0, st, sv, rays, n, ids, ts); break;
+#define PT_LAUNCH(F, W) hipLaunchKernelGGL((k_trace_closest<F, W>), grid, block, 0, st, sv, rays, n, ids, ts)
+    PT_FOR_VARIANT(variant, PT_LAUNCH)
+#undef PT_LAUNCH
+}
+
+// The entry kinds of a world list as the signature templates name them; 0 = none of them.
+int world_kind(const PtSceneDesc* d, int i)
+{
+    const PtObject& o = d->world[i];
+    if (o.type != PT_OBJ_SHAPE) return 0;
+    const PtShape& s = d->shapes[o.index];
+    if (s.xform_count == 0) {
+        switch (s.type) {
+        case PT_SHAPE_RECT_XY: return WK_RECT_XY;
+        case PT_SHAPE_RECT_XZ: return WK_RECT_XZ;
+        case PT_SHAPE_RECT_YZ: return WK_RECT_YZ;
+        case PT_SHAPE_SPHERE: return WK_SPHERE;
+        default: return 0;
+        }
     }
+    if (s.type == PT_SHAPE_BOX && s.xform_count == 2 && d->xforms[s.xform_first].type == PT_XFORM_TRANSLATE &&
+        d->xforms[s.xform_first + 1].type == PT_XFORM_ROTATE_Y) return WK_BOX_TR;
+    return 0;
+}
+template <int... K>
+bool world_matches(const PtSceneDesc* d, WorldSig<K...>)
+{
+    const int kinds[] = { K... };
+    if (d->n_world != (int)sizeof...(K)) return false;
+    for (int i = 0; i < d->n_world; i++)
+        if (world_kind(d, i) != kinds[i]) return false;
+    return true;
 }
 
 }  // namespace
@@ -493,6 +521,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     }
     sc->mask = mask;
     sc->variant = pick_variant(mask);
+    if (sc->variant == 0 && world_matches(desc, CornellWorld{})) sc->variant = V_CORNELL_WORLD;
     if (sc->variant < 0) { pt::set_error("pt_scene_create: no kernel specialisation covers this scene"); pt_scene_destroy(sc); return PT_ERR_UNSUPPORTED; }
     {
         void* ctr = nullptr;
@@ -593,6 +622,7 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
         sc->last.schedule = ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
+        sc->last.signature_walk = sc->variant == V_CORNELL_WORLD ? 1 : 0;
     }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
@@ -648,6 +678,7 @@ extern "C" int pt_render_pass(PtScene* sc, const PtRenderParams* p, void* d_accu
     sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
     sc->last.pipeline = PT_PIPELINE_FUSED;
     sc->last.schedule = PT_SCHEDULE_TILES;
+    sc->last.signature_walk = sc->variant == V_CORNELL_WORLD ? 1 : 0;
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->have_timing = true;

@@ -48,7 +48,8 @@ constexpr uint32_t M_TRIMESH = F_RECT | F_TRIANGLE | F_LIGHTS | F_LBVH;
 constexpr uint32_t M_ALL = F_ALL & ~F_LBVH;
 constexpr uint32_t M_ALL_LBVH = F_ALL;
 
-constexpr int N_VARIANTS = 6;
+constexpr int N_VARIANTS = 7;
+constexpr int V_CORNELL_WORLD = 6;    // M_CORNELL with the CornellWorld signature walk (the fused kernels and the closest-hit kernel)
 }  // namespace ptk
 
 struct PtScene {

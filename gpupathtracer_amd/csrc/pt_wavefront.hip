@@ -291,7 +291,7 @@ void launch_round_variant(int variant, const SceneView& sv, const RenderArgs& ra
 {
     using namespace ptk;
     switch (variant) {
-    case 0: launch_round<M_CORNELL>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case 0: case V_CORNELL_WORLD: launch_round<M_CORNELL>(sv, ra, w, parity, nq, blocks, out, st); break;
     case 1: launch_round<M_SPHERES>(sv, ra, w, parity, nq, blocks, out, st); break;
     case 2: launch_round<M_SPHERES_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
     case 3: launch_round<M_TRIMESH>(sv, ra, w, parity, nq, blocks, out, st); break;

@@ -212,7 +212,7 @@ typedef struct PtRenderStats {
     int32_t  pipeline;       /* scheduler that ran                                        */
     uint64_t paths;          /* camera samples traced by this call (this shard only)      */
     int32_t  schedule;       /* PtSchedule the fused pipeline ran (TILES or REFILL), else 0 */
-    int32_t  reserved0;
+    int32_t  signature_walk; /* 1 when the world list matched a compiled-in signature (straight-line walk) */
     uint64_t reserved[3];
 } PtRenderStats;
 
