@@ -104,11 +104,11 @@ def main():
     kernel_ms = []
 
     by_samples = args.shard == "samples" and world > 1
-    if by_samples and args.spp % world:
+    if world > 1 and args.spp % world and by_samples:
         raise SystemExit("bench.py: --shard samples needs spp divisible by the number of GPUs")
 
-    def step(record):
-        if by_samples:        # raw sums of this rank's batch; added by the reduce, averaged + gamma'd once on the root
+    def step(record, samples):
+        if samples:           # raw sums of this rank's batch; added by the reduce, averaged + gamma'd once on the root
             scene.render_device(frame.ptr, nx, ny, args.spp // world, args.depth, batch_index=rank, batch_count=world, raw_sum=1)
         else:
             scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, shard_index=rank, shard_count=world, tile=(8, 8))
@@ -121,30 +121,40 @@ def main():
                 import torch
                 host = torch.from_numpy(frame.to_host())
                 dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if by_samples and rank == 0:
+                if samples and rank == 0:
                     frame.from_host(host.numpy())
-            if by_samples and rank == 0:
+            if samples and rank == 0:
                 pt.frame_finish(frame.ptr, n_floats, args.spp)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step(False)
-    pt.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    pt.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(samples, record):
+        for _ in range(args.warmup):
+            step(False, samples)
+        pt.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(record, samples)
+        pt.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    dt = timed(by_samples, True)
+    # Beside the headline (tile shards: the reference's image bit for bit), the same frame with the
+    # samples of every pixel split over the ranks: the other sharding the task names, equal to the
+    # reference's image up to sampling noise only.  Reported, never used for `value`.
+    dt_samples = None
+    if world > 1 and not by_samples and args.spp % world == 0:
+        dt_samples = timed(True, False)
 
     paths_per_step = nx * ny * args.spp
     value = paths_per_step * args.steps / dt / 1e6
@@ -190,6 +200,11 @@ def main():
                        "pipeline": "fused", "collective": collective},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if dt_samples is not None:
+            result["sample_batch_sharding"] = {
+                "value": paths_per_step * args.steps / dt_samples / 1e6, "unit": "Mpaths/s", "ms_per_step": dt_samples / args.steps * 1e3,
+                "note": "every rank traces spp/N samples of every pixel from its own seeds, raw sums reduced, finished on rank 0; "
+                        "not the reference's random sequence (PSNR-tested), not part of `value`"}
     if comm is not None:
         comm.close()
     if dist is not None:
