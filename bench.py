@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 
 # Algorithmic work of one path under the reference's arithmetic (one FLOP = one fp32
 # add/sub/mul/compare/min/max/div/sqrt, no FMA credit because parity forbids contraction), counted
-# by the instrumented build of the CPU checker: bench/work_model.py -> bench/work_model.json.
+# by the instrumented build of the CPU checker: tests/make_work_model.py -> bench/work_model.json.
 # Cornell: 52.4 rectangle tests, 2.81 closest-hit searches, 1.81 diffuse scatters, 799 FLOP per path.
 with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
     FLOP_PER_PATH = {k: v["flop_per_path"] for k, v in json.load(_f)["configs"].items()}

@@ -1,4 +1,4 @@
-"""Quick GPU check used while optimising (not collected by pytest): bit-exactness on all scenes + Cornell throughput."""
+"""Quick GPU check used while optimising (not a test): bit-exactness on all scenes + Cornell throughput."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

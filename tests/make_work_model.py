@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # the repository root
 sys.path.insert(0, ROOT)
 import gpupathtracer_amd as pt                     # noqa: E402
 from gpupathtracer_amd import _abi as A            # noqa: E402
@@ -41,7 +41,7 @@ def main():
     lib.oracle_work_counters.argtypes = [C.c_void_p, C.c_int]
     out = {"convention": "FLOP = fp32 add/sub/mul/compare/min/max/div/sqrt as the reference evaluates them "
                          "(flat lists, hit record completed on every accepted hit); no FMA credit; libm and integer ops separate",
-           "generator": "bench/work_model.py (oracle/pt_oracle.c built with -DPT_ORACLE_COUNT)", "configs": {}}
+           "generator": "tests/make_work_model.py (oracle/pt_oracle.c built with -DPT_ORACLE_COUNT)", "configs": {}}
     for key, scene, aspect, nx, ny, ns, note in CONFIGS:
         desc = pt.builtin_scene(scene, aspect)
         p = A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=25, shard_index=0, shard_count=1, tile_w=8, tile_h=8)
