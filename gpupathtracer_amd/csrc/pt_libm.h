@@ -138,28 +138,52 @@ PT_HD float cosf_glibc(float y)
 
 
 // sinf_glibc(y) and cosf_glibc(y) with one shared range reduction; the two results are the same
-// bits as the separate calls (both evaluate their polynomial on the same reduced argument).
+// bits as the separate calls.  Both polynomials are evaluated once on the reduced argument and the
+// quadrant only picks which result is the sine and which signs they carry: negating x negates the
+// odd polynomial exactly, and the sign-folded coefficient set negates the even one exactly
+// (round-to-nearest is symmetric), so no lane evaluates a polynomial twice and a wave whose lanes
+// sit in different quadrants does not diverge.  Below pi/4 the reduction yields n = 0 and returns
+// x itself, so that range needs no branch of its own.
 PT_HD void sincosf_glibc(float y, float* sp, float* cp)
 {
     double x = y;
-    int n;
-    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
-        if (abstop12(y) < abstop12(0x1p-12f)) { *sp = y; *cp = 1.0f; return; }
-        const double x2 = x * x;
-        *sp = sincos_poly(x, x2, false, 0);
-        *cp = sincos_poly(x, x2, false, 1);
+    int n, q;
+    if (abstop12(y) < abstop12(0x1p-12f)) {     // also keeps the sign of a zero argument
+        *sp = y; *cp = 1.0f;
+        return;
+    }
+    if (abstop12(y) < abstop12(120.0f)) {
+        x = reduce_fast(x, &n);
+        q = n;
     } else if (abstop12(y) < 0x7f8) {
-        int q;
-        if (abstop12(y) < abstop12(120.0f)) { x = reduce_fast(x, &n); q = n; }
-        else { const uint32_t xi = f2u(y); x = reduce_large(xi, &n); q = n + (int)(xi >> 31); }
-        const double s = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;
-        const bool neg = (q & 2) != 0;
-        const double xs = x * s, x2 = x * x;
-        *sp = sincos_poly(xs, x2, neg, n);
-        *cp = sincos_poly(xs, x2, neg, n ^ 1);
+        const uint32_t xi = f2u(y);
+        x = reduce_large(xi, &n);
+        q = n + (int)(xi >> 31);
     } else {
         *sp = y - y; *cp = y - y;
+        return;
     }
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double x2 = x * x;
+    const double x3 = x * x2, x4 = x2 * x2;
+    const double ts = __builtin_fma(x2, s3, s2);
+    const double tc2 = __builtin_fma(x2, c4, c3);
+    const double tc1 = __builtin_fma(x2, c1, c0);
+    const double x7 = x3 * x2, x6 = x4 * x2;
+    const double s = __builtin_fma(x3, s1, x);
+    const double c = __builtin_fma(x4, c2, tc1);
+    const uint32_t odd = f2u((float)__builtin_fma(x7, ts, s));     // sine polynomial of +x
+    const uint32_t even = f2u((float)__builtin_fma(x6, tc2, c));   // cosine polynomial, positive set
+    // sign of the odd polynomial: x was multiplied by -1 in quadrants 1 and 2 of q;
+    // sign of the even one: the negated coefficient set is used when q & 2.
+    const uint32_t odd_sign = (uint32_t)(((q & 3) == 1 || (q & 3) == 2) ? 1 : 0) << 31;
+    const uint32_t even_sign = (uint32_t)((q >> 1) & 1) << 31;
+    const uint32_t o = odd ^ odd_sign, e = even ^ even_sign;
+    uint32_t sb = (n & 1) ? e : o, cb = (n & 1) ? o : e;
+    memcpy(sp, &sb, 4);
+    memcpy(cp, &cb, 4);
 }
 
 PT_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
