@@ -176,7 +176,8 @@ class Comm:
 
 
 def libm_eval(fn, x, on_device):
-    """fn: 0 sin, 1 cos, 2 log, 3 x**5 -- the library's libm replacements on float32 inputs."""
+    """fn: 0 sin, 1 cos, 2 log, 3 x**5, 4/5 sine/cosine of the combined evaluation -- the library's
+    libm replacements on float32 inputs."""
     x = np.ascontiguousarray(x, np.float32)
     out = np.empty_like(x)
     _check(library().pt_libm_eval(int(fn), x.ctypes.data, x.size, out.ctypes.data, 1 if on_device else 0))

@@ -34,7 +34,8 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
     case 0: r = ptm::sinf_glibc(v); break;
     case 1: r = ptm::cosf_glibc(v); break;
     case 2: r = ptm::logf_glibc(v); break;
-    default: r = ptm::pow5f_glibc(v); break;
+    case 3: r = ptm::pow5f_glibc(v); break;
+    default: { float sn, cs; ptm::sincosf_glibc(v, &sn, &cs); r = fn == 4 ? sn : cs; } break;
     }
     out[i] = r;
 }
@@ -128,7 +129,7 @@ extern "C" void pt_comm_destroy(PtComm* c)
 
 extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device)
 {
-    if (fn < 0 || fn > 3 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
+    if (fn < 0 || fn > 5 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
     if (n == 0) return PT_OK;
     if (!on_device) {
         for (size_t i = 0; i < n; i++) {
@@ -136,7 +137,8 @@ extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on
             case 0: out[i] = ptm::sinf_glibc(x[i]); break;
             case 1: out[i] = ptm::cosf_glibc(x[i]); break;
             case 2: out[i] = ptm::logf_glibc(x[i]); break;
-            default: out[i] = ptm::pow5f_glibc(x[i]); break;
+            case 3: out[i] = ptm::pow5f_glibc(x[i]); break;
+            default: { float sn, cs; ptm::sincosf_glibc(x[i], &sn, &cs); out[i] = fn == 4 ? sn : cs; } break;
             }
         }
         return PT_OK;

@@ -292,11 +292,17 @@ void launch_trace(int variant, const SceneView& sv, const PtRay* rays, size_t n,
 }
 
 // The entry kinds of a world list as the signature templates name them; 0 = none of them.
+// A shape whose constants are not finite or exceed 2^58 in magnitude has no kind: the signature
+// walk's shortened division (rcp_refined) relies on that bound for its numerators.
 int world_kind(const PtSceneDesc* d, int i)
 {
     const PtObject& o = d->world[i];
     if (o.type != PT_OBJ_SHAPE) return 0;
     const PtShape& s = d->shapes[o.index];
+    auto tame = [](const float* v, int n) { for (int j = 0; j < n; j++) if (!(std::fabs(v[j]) <= ptd::RCP_BIG)) return false; return true; };
+    if (!tame(s.p, (int)(sizeof(s.p) / sizeof(s.p[0])))) return 0;
+    for (int x = 0; x < s.xform_count; x++)
+        if (!tame(d->xforms[s.xform_first + x].v, (int)(sizeof(d->xforms[0].v) / sizeof(float)))) return 0;
     if (s.xform_count == 0) {
         switch (s.type) {
         case PT_SHAPE_RECT_XY: return WK_RECT_XY;

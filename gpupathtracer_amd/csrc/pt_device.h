@@ -236,13 +236,48 @@ __device__ __forceinline__ V3 msphere_center(const float* q, float time)
     V3 c0 = mk(q[0], q[1], q[2]), c1 = mk(q[3], q[4], q[5]);
     return c0 + ((time - q[6]) / (q[7] - q[6])) * (c1 - c0);
 }
+// ---- division by a denominator in a stated range ------------------------------------------------------
+// `n / d` in single precision compiles to the IEEE sequence
+//     ds, ns = v_div_scale(d), v_div_scale(n);  r0 = v_rcp(ds);  e = fma(-ds, r0, 1);  r = fma(e, r0, r0);
+//     q = ns * r;  e = fma(-ds, q, ns);  q = fma(e, r, q);  e = fma(-ds, q, ns);  q = v_div_fmas(e, r, q);
+//     v_div_fixup(q, d, n)
+// whose first and last three instructions only act outside a range of operands: with
+// 2^-30 <= |d| <= 2^60 and 2^-103 <= |n| <= 2^60 both v_div_scale return their operand unchanged and
+// clear VCC, v_div_fmas is then a plain fma and v_div_fixup passes q through.  Inside that range the
+// eight instructions in between are therefore the whole division, bit for bit, and the two that
+// depend on d alone can be shared by every numerator over the same denominator.  A numerator below
+// 2^-103 in magnitude (zero included) gives a finite |q| < 2^-70 here and |n / d| < 2^-70 there:
+// not the same bits, but callers that discard every quotient below a bound larger than that see
+// no difference (the rectangle test below discards t < tmin).
+struct Rcp { float nd, r; };                               // -d and the refined reciprocal of d
+__device__ __forceinline__ Rcp rcp_refined(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    Rcp c; c.nd = -d; c.r = __builtin_fmaf(e, r0, r0);
+    return c;
+}
+__device__ __forceinline__ float quot(float n, const Rcp& c)
+{
+    float q = n * c.r;
+    float e = __builtin_fmaf(c.nd, q, n);
+    q = __builtin_fmaf(e, c.r, q);
+    e = __builtin_fmaf(c.nd, q, n);
+    return __builtin_fmaf(e, c.r, q);
+}
+__device__ __forceinline__ float quot(float n, float d) { return n / d; }
+// The range test for `count` denominators at once and for the origin the numerators are formed from.
+constexpr float RCP_D_MIN = 0x1p-30f, RCP_BIG = 0x1p58f, RCP_TMIN_MIN = 0x1p-20f;
+
 // X?Rectangle::hit (src/ptRectangle.cu:12-28,66-82,120-136): inclusive range.
-// (ok,dk) plane axis, (oa,da) and (ob,db) the two in-plane axes.
-__device__ __forceinline__ bool rect_t(float ok, float dk, float oa, float da, float ob, float db,
+// (ok,dk) plane axis, (oa,da) and (ob,db) the two in-plane axes; dk is the direction component
+// itself or its refined reciprocal (only where t0 >= RCP_TMIN_MIN, see above).
+template <class D>
+__device__ __forceinline__ bool rect_t(float ok, const D& dk, float oa, float da, float ob, float db,
                                        float a0, float a1, float b0, float b1, float k,
                                        float t0, float t1, float& t)
 {
-    float tt = (k - ok) / dk;
+    float tt = quot(k - ok, dk);
     if (tt < t0 || tt > t1) return false;
     float a = oa + tt * da;
     float b = ob + tt * db;
@@ -252,19 +287,26 @@ __device__ __forceinline__ bool rect_t(float ok, float dk, float oa, float da, f
 }
 // Box = list of six rectangles searched with a shrinking upper bound
 // (include/ptRectangle.h:199-217, src/ptHitableList.cu:12-27): a later face wins ties.
-__device__ __forceinline__ bool box_t(const float* q, const Ray& r, float t0, float t1, float& t, int& face)
+// (dx, dy, dz): the ray's direction components as rect_t takes them.
+template <class D>
+__device__ __forceinline__ bool box_t(const float* q, const Ray& r, const D& dx, const D& dy, const D& dz,
+                                      float t0, float t1, float& t, int& face)
 {
     const float x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
     bool any = false;
     float closest = t1, tt;
-    if (rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z1, t0, closest, tt)) { any = true; closest = tt; face = 0; }
-    if (rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z0, t0, closest, tt)) { any = true; closest = tt; face = 1; }
-    if (rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y1, t0, closest, tt)) { any = true; closest = tt; face = 2; }
-    if (rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y0, t0, closest, tt)) { any = true; closest = tt; face = 3; }
-    if (rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x1, t0, closest, tt)) { any = true; closest = tt; face = 4; }
-    if (rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x0, t0, closest, tt)) { any = true; closest = tt; face = 5; }
+    if (rect_t(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z1, t0, closest, tt)) { any = true; closest = tt; face = 0; }
+    if (rect_t(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z0, t0, closest, tt)) { any = true; closest = tt; face = 1; }
+    if (rect_t(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y1, t0, closest, tt)) { any = true; closest = tt; face = 2; }
+    if (rect_t(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y0, t0, closest, tt)) { any = true; closest = tt; face = 3; }
+    if (rect_t(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x1, t0, closest, tt)) { any = true; closest = tt; face = 4; }
+    if (rect_t(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x0, t0, closest, tt)) { any = true; closest = tt; face = 5; }
     t = closest;
     return any;
+}
+__device__ __forceinline__ bool box_t(const float* q, const Ray& r, float t0, float t1, float& t, int& face)
+{
+    return box_t(q, r, r.d.x, r.d.y, r.d.z, t0, t1, t, face);
 }
 // Triangle::hit (src/ptTriangle.cu:28-72): Moller-Trumbore with back-face cull; the value
 // compared against the range and reported is dot(edge2,qvec) WITHOUT the 1/det factor.
@@ -598,16 +640,17 @@ template <int... K> struct WorldSig { static constexpr int count = (int)sizeof..
 // cornell_box (src/ptMain.cu:286-317): five walls and the lamp, then the two Translate(RotateY(Box))
 using CornellWorld = WorldSig<WK_RECT_YZ, WK_RECT_YZ, WK_RECT_XZ, WK_RECT_XZ, WK_RECT_XZ, WK_RECT_XY, WK_BOX_TR, WK_BOX_TR>;
 
-template <uint32_t F, int KIND>
-__device__ __forceinline__ void world_entry(const SceneView& sv, int k, const Ray& r, float tmin, float& closest, bool& any, Hit& h)
+template <uint32_t F, int KIND, bool TAME, class D>
+__device__ __forceinline__ void world_entry(const SceneView& sv, int k, const Ray& r, const D& dx, const D& dy, const D& dz,
+                                            float tmin, float& closest, bool& any, Hit& h)
 {
     const int id = sv.world[k].index;
     const PtShape* s = &sv.shapes[id];
     float t = 0; int face = 0;
     bool hit = false;
-    if (KIND == WK_RECT_XY) hit = rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
-    if (KIND == WK_RECT_XZ) hit = rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
-    if (KIND == WK_RECT_YZ) hit = rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
+    if (KIND == WK_RECT_XY) hit = rect_t(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
+    if (KIND == WK_RECT_XZ) hit = rect_t(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
+    if (KIND == WK_RECT_YZ) hit = rect_t(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
     if (KIND == WK_SPHERE) hit = sphere_t(mk(s->p[0], s->p[1], s->p[2]), s->p[3], r, tmin, closest, t);
     if (KIND == WK_BOX_TR) {                               // Translate(RotateY(Box)): to_local's arithmetic, written out
         const PtXform tr = sv.xforms[s->xform_first], ro = sv.xforms[s->xform_first + 1];
@@ -616,20 +659,40 @@ __device__ __forceinline__ void world_entry(const SceneView& sv, int k, const Ra
         const float sinT = ro.v[0], cosT = ro.v[1];
         const float ox = cosT * lr.o.x - sinT * lr.o.z;
         const float oz = sinT * lr.o.x + cosT * lr.o.z;
-        const float dx = cosT * lr.d.x - sinT * lr.d.z;
-        const float dz = sinT * lr.d.x + cosT * lr.d.z;
-        lr.o.x = ox; lr.o.z = oz; lr.d.x = dx; lr.d.z = dz;
-        hit = box_t(s->p, lr, tmin, closest, t, face);
+        const float ldx = cosT * lr.d.x - sinT * lr.d.z;
+        const float ldz = sinT * lr.d.x + cosT * lr.d.z;
+        lr.o.x = ox; lr.o.z = oz; lr.d.x = ldx; lr.d.z = ldz;
+        if constexpr (TAME) {
+            // the rotation keeps d.y (shared reciprocal) and at most doubles magnitudes; what is left
+            // to test is that the turned components did not cancel and that the local origin is tame
+            const bool tame = fabsf(lr.o.x) + fabsf(lr.o.y) + fabsf(lr.o.z) <= RCP_BIG && fabsf(ldx) >= RCP_D_MIN && fabsf(ldz) >= RCP_D_MIN;
+            if (tame) hit = box_t(s->p, lr, rcp_refined(ldx), dy, rcp_refined(ldz), tmin, closest, t, face);
+            else hit = box_t(s->p, lr, tmin, closest, t, face);
+        } else {
+            hit = box_t(s->p, lr, tmin, closest, t, face);
+        }
     }
     if (hit) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
 }
+// Rays whose origin and direction components lie in the range where the shortened division is
+// the whole division (see rcp_refined) take it, with one reciprocal per axis; any other ray
+// (an axis-parallel direction, an overflowing origin, NaN) takes the compiler's full sequence.
+// The scene's own constants are range-checked when the signature is matched on the host.
 template <uint32_t F, int... K>
 __device__ __forceinline__ bool world_hit_sig(const SceneView& sv, const Ray& r, float tmin, float tmax, Hit& h, WorldSig<K...>)
 {
     bool any = false;
     float closest = tmax;
     int k = 0;
-    ((world_entry<F, K>(sv, k++, r, tmin, closest, any, h)), ...);
+    const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+    const bool tame = tmin >= RCP_TMIN_MIN && fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) <= RCP_BIG && ax + ay + az <= RCP_BIG &&
+                      ax >= RCP_D_MIN && ay >= RCP_D_MIN && az >= RCP_D_MIN;
+    if (tame) {
+        const Rcp cx = rcp_refined(r.d.x), cy = rcp_refined(r.d.y), cz = rcp_refined(r.d.z);
+        ((world_entry<F, K, true>(sv, k++, r, cx, cy, cz, tmin, closest, any, h)), ...);
+    } else {
+        ((world_entry<F, K, false>(sv, k++, r, r.d.x, r.d.y, r.d.z, tmin, closest, any, h)), ...);
+    }
     return any;
 }
 template <class W> struct is_any_world { static constexpr bool value = false; };

@@ -76,9 +76,10 @@ def test_libm_host_build_matches_glibc(oracle):
     x = np.concatenate([rng.uniform(-130, 130, 400_000), rng.uniform(-7, 7, 400_000),
                         (10.0 ** rng.uniform(-38, 38, 200_000)) * rng.choice([-1, 1], 200_000),
                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 120.0, 0.78539816])]).astype(np.float32)
-    for fn, arg in ((0, x), (1, x), (2, np.abs(x)), (3, np.clip(x, -4, 4))):
+    # 4 and 5: sine and cosine out of the combined evaluation, checked against libm's sinf and cosf
+    for fn, arg in ((0, x), (1, x), (2, np.abs(x)), (3, np.clip(x, -4, 4)), (4, x), (5, x)):
         a = pt.libm_eval(fn, arg, on_device=False)
-        b = oracle.libm(fn, arg)
+        b = oracle.libm(fn - 4 if fn >= 4 else fn, arg)
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (fn, arg[~same][:5])
 

@@ -177,9 +177,10 @@ def test_device_libm_matches_glibc(oracle):
     x = np.concatenate([rng.uniform(-130, 130, 1_000_000), rng.uniform(-7, 7, 1_000_000),
                         (10.0 ** rng.uniform(-38, 38, 500_000)) * rng.choice([-1, 1], 500_000),
                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 120.0, 0.78539816])]).astype(np.float32)
-    for fn, arg in ((0, x), (1, x), (2, np.abs(x)), (3, np.clip(x, -4, 4))):
+    # 4 and 5: sine and cosine out of the combined evaluation, checked against libm's sinf and cosf
+    for fn, arg in ((0, x), (1, x), (2, np.abs(x)), (3, np.clip(x, -4, 4)), (4, x), (5, x)):
         a = pt.libm_eval(fn, arg, on_device=True)
-        b = oracle.libm(fn, arg)
+        b = oracle.libm(fn - 4 if fn >= 4 else fn, arg)
         same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (fn, arg[~same][:5], a[~same][:5], b[~same][:5])
 
@@ -483,3 +484,47 @@ def test_signature_walk_and_generic_walk_agree(oracle):
         ids, ts = scene.trace_closest(rays)
         oid, ot = oracle.trace_closest(desc, rays)
         assert (ids == oid).all() and (bits(ts) == bits(ot)).all()
+
+
+def test_signature_walk_division_range_edges(oracle):
+    """The signature walk divides with a shortened sequence when a ray's origin and direction lie in
+    the range where that sequence is the whole IEEE division, and with `/` otherwise.  Rays on and
+    around every edge of that range (axis-parallel, denormal and huge components, origins on the
+    walls, infinities, NaN) must give the oracle's hit and the oracle's t bit for bit either way."""
+    d = pt.builtin_scene("cornell", 1.0)
+    sc = pt.Scene(d)
+    rng = np.random.default_rng(11)
+    n = 120_000
+    rays = random_rays(rng, n, -100, 700)
+    special_d = np.array([0.0, -0.0, 1e-45, -1e-40, 2.0 ** -31, -2.0 ** -30, 2.0 ** -30 * 1.0000001, 1e-12, -1e-9, 1e-5,
+                          2.0 ** 57, -2.0 ** 58, 2.0 ** 59, 1e30, -3e38, np.inf, -np.inf, np.nan], np.float32)
+    special_o = np.array([0.0, -0.0, 555.0, 554.0, 213.0, 343.0, 227.0, 332.0, 1e-45, -1e-30, 2.0 ** 57, -2.0 ** 58 * 0.9,
+                          2.0 ** 58, 1e25, -3e38, np.inf, np.nan, 130.0, 265.0, 295.0, 65.0], np.float32)
+    for comp in ("d", "o"):
+        table = special_d if comp == "d" else special_o
+        for _ in range(3):                                    # one, two and three components replaced
+            idx = rng.integers(0, n, n // 3)
+            axis = rng.integers(0, 3, idx.size)
+            rays[comp][idx, axis] = table[rng.integers(0, table.size, idx.size)]
+    ids_o, t_o = oracle.trace_closest(d, rays)
+    ids_g, t_g = sc.trace_closest(rays)
+    sc.render(8, 8, 1)
+    assert sc.stats().signature_walk == 1
+    np.testing.assert_array_equal(ids_g, ids_o)
+    same = (bits(t_g) == bits(t_o)) | (np.isnan(t_g) & np.isnan(t_o))
+    assert same.all(), (rays[~same][:5], t_g[~same][:5], t_o[~same][:5])
+    assert (ids_o != abi.ID_MISS).mean() > 0.2
+
+    # a box whose constants leave the range the shortened division needs is walked generically
+    from tests._desc_tools import OwnedDesc
+    g = OwnedDesc(d)
+    g.lists["shapes"][g.lists["world"][3].index].p[4] = 2.0 ** 59      # the floor's plane, far away
+    g.finalize()
+    sg = pt.Scene(g)
+    ids_g, t_g = sg.trace_closest(rays[:20000])
+    sg.render(8, 8, 1)
+    assert sg.stats().signature_walk == 0
+    ids_o, t_o = oracle.trace_closest(g, rays[:20000])
+    np.testing.assert_array_equal(ids_g, ids_o)
+    same = (bits(t_g) == bits(t_o)) | (np.isnan(t_g) & np.isnan(t_o))
+    assert same.all()
