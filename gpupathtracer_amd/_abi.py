@@ -11,7 +11,7 @@ OBJ_SHAPE, OBJ_MEDIUM, OBJ_BVH = 1, 2, 3
 AMBIENT_NONE, AMBIENT_CONSTANT, AMBIENT_SKY = 0, 1, 2
 ACCEL_LIST, ACCEL_LBVH = 0, 1
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
-SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL = 0, 1, 2
+SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL, SCHEDULE_WALK = 0, 1, 2, 3
 STREAM_KEEP_AMBIENT_COLOR = 1
 ID_MISS = -1
 ID_MEDIUM_BASE = 0x40000000

@@ -29,10 +29,11 @@ using namespace ptk;
 // leaves the rectangle-scene kernel at 5 waves per SIMD and the full-feature kernels at 2; the
 // values below measured fastest on MI355X: Cornell 1024^2 124.5 -> 118.9 ms at 6 (7: 122.2, 8: 125.6,
 // spills), final scene 54.4 -> 40.5 ms at 4 (3: 43.3, 6: 40.9), 2M-triangle field 40.7 -> 33.1 ms at 6
-// (the LDS traversal stack allows six workgroups per CU; 8 with a shorter stack measured the same).
+// (the LDS traversal stack allows six workgroups per CU; 8 with a shorter stack measured the same),
+// sphere scene in the LBVH 16.9 -> 13.0 ms at 6 (3: 16.9, 4: 14.5, 5: 13.5).
 __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 {
-    return (F & F_REFBVH) ? 4 : (F == M_CORNELL) ? 6 : (F == M_TRIMESH) ? 6 : 1;
+    return (F & F_REFBVH) ? 4 : (F == M_CORNELL) ? 6 : (F == M_SPHERES_LBVH) ? 6 : (F == M_TRIMESH) ? 6 : 1;
 }
 
 // One lane's path tracer state: the pixel's random stream, its running sum and the path in flight.
@@ -215,6 +216,95 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
     }
 }
 
+// Fused scheduler for worlds held in the library's LBVH: persistent lanes as in k_render_refill, and
+// the closest-hit search is shared by the wave one tree step at a time.  Lanes whose search has
+// ended wait; when WALK_WAIT_LANES of them wait (or nobody is left walking) the wave leaves the
+// search loop, those lanes shade, scatter or start their next sample (or pixel) and begin their
+// next search, and the wave steps again -- lanes that were still walking simply carry on.  With one
+// search per lane_step call the wave instead runs every search to the end of its longest walk: on
+// the sphere scene 28 % of the VALU lanes did work, on the 2 M-triangle field 8 %.  What each lane
+// computes, and the order of its random draws, is unchanged (the search draws none).
+template <uint32_t F>
+__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneView sv, RenderArgs ra, float* __restrict__ out,
+                                                                           unsigned* __restrict__ next_slot)
+{
+    static_assert((F & F_LBVH) != 0, "the shared walk is the LBVH walk");
+    __shared__ int lds_stack[4 * 64 * LBVH_LDS_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    int* my_stack = &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane];
+    const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
+    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    enum { NEED_PIXEL, NEXT_RAY, WALKING, WALKED, DONE };
+    LaneState st;
+    lane_init(st);
+    LbvhWalk w;
+    lbvh_begin(sv, st.ray, FLT_MAX, w);
+    int spill[LBVH_STACK - LBVH_LDS_STACK];
+    unsigned i = 0;
+    int mode = NEED_PIXEL;
+    while (true) {
+        if (mode == WALKED) {                                 // the rest of the bounce, as in lane_step
+            Hit h;
+            h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
+            bool ended;
+            if (w.any) {
+                h.t = w.best; h.id = w.best_id; h.face = w.best_face;
+                ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
+            } else {
+                shade_miss<F>(sv, st.ray, st.thr);
+                ended = true;
+            }
+            st.depth++;
+            if (!ended && st.depth >= ra.max_depth) ended = true;      // bounce limit: the running product is the sample
+            mode = NEXT_RAY;
+            if (ended) {
+                if (!(st.thr.x == st.thr.x)) st.thr.x = 0;
+                if (!(st.thr.y == st.thr.y)) st.thr.y = 0;
+                if (!(st.thr.z == st.thr.z)) st.thr.z = 0;
+                st.accum = st.accum + st.thr;
+                st.s++;
+                st.fresh = true;
+                if (st.s >= ra.ns) { lane_write_pixel(st, ra, i, out); mode = NEED_PIXEL; }
+            }
+        }
+        if (mode == NEED_PIXEL) {
+            const unsigned long long need = __ballot(1);      // one atomic per wave for all lanes that ran dry
+            const int leader = __ffsll((long long)need) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(next_slot, (unsigned)__popcll(need));
+            base = __shfl(base, leader);
+            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const unsigned slot = base + (unsigned)__popcll(need & lower);
+            int x, ytop;
+            if (slot >= total_slots) mode = DONE;             // the shard is exhausted
+            else if (wave_pixel(ra, (int)(slot >> 6), (int)(slot & 63), x, ytop)) { lane_begin_pixel(st, ra, x, ytop, i); mode = NEXT_RAY; }
+            // else: a slot beyond the image edge; ask again next round
+        }
+        if (mode == NEXT_RAY) {
+            if (st.fresh) {                                   // render_pixel, src/ptMain.cu:158-160
+                float u = ((float)st.x + st.rng.rand()) / fnx;
+                float v = ((float)st.y + st.rng.rand()) / fny;
+                st.ray = camera_ray(sv, u, v, st.rng);
+                st.thr = mk(1, 1, 1);
+                st.depth = 0;
+                st.fresh = false;
+            }
+            lbvh_begin(sv, st.ray, FLT_MAX, w);
+            mode = WALKING;
+        }
+        const int live = __popcll(__ballot(mode != DONE));
+        if (live == 0) break;
+        while (true) {
+            const int walking = __popcll(__ballot(mode == WALKING));
+            if (walking == 0 || live - walking >= ra.walk_wait) break;
+            if (mode == WALKING) {
+                if (lbvh_step<F>(sv, st.ray, 0.001f, FLT_MAX, w, my_stack, spill)) mode = WALKED;
+            }
+        }
+    }
+}
+
 template <uint32_t F, class W>
 __global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay* __restrict__ rays, size_t n,
                                                        int32_t* __restrict__ prim_id, float* __restrict__ t_out)
@@ -262,14 +352,23 @@ int pick_variant(uint32_t scene_mask)
     default: LAUNCH(M_CORNELL, CornellWorld); break;          \
     }
 
+template <uint32_t F>
+void launch_walk(dim3 grid, dim3 block, hipStream_t st, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot)
+{
+    if constexpr ((F & F_LBVH) != 0) hipLaunchKernelGGL((k_render_walk<F>), grid, block, 0, st, sv, ra, out, next_slot);
+}
+
 void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
 {
     // REFILL: persistent grid of at most 32 waves per CU, the rest of the shard comes from the counter.
+    // A world in the LBVH is searched by the wave-shared walk (which ends a path at the bounce
+    // limit after a shade, so a limit of zero bounces stays with the plain refill kernel).
     const bool refill = ra.refill != 0;
     const int tiles4 = (ra.n_wave_tiles + 3) / 4;
     const dim3 block(256), grid(refill ? std::min(tiles4, 2048) : tiles4);
 #define PT_LAUNCH(F, W)                                                                                        \
-    if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot);      \
+    if (ra.refill == 2) launch_walk<F>(grid, block, st, sv, ra, out, next_slot);                               \
+    else if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot);  \
     else hipLaunchKernelGGL((k_render_tiles<F, W>), grid, block, 0, st, sv, ra, out)
     PT_FOR_VARIANT(variant, PT_LAUNCH)
 #undef PT_LAUNCH
@@ -600,13 +699,25 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (p->pipeline != PT_PIPELINE_DEFAULT && p->pipeline != PT_PIPELINE_FUSED && p->pipeline != PT_PIPELINE_WAVEFRONT) {
         pt::set_error("render: unknown pipeline"); return PT_ERR_INVALID;
     }
-    if (p->schedule != PT_SCHEDULE_AUTO && p->schedule != PT_SCHEDULE_TILES && p->schedule != PT_SCHEDULE_REFILL) {
+    if (p->schedule != PT_SCHEDULE_AUTO && p->schedule != PT_SCHEDULE_TILES && p->schedule != PT_SCHEDULE_REFILL &&
+        p->schedule != PT_SCHEDULE_WALK) {
         pt::set_error("render: unknown schedule"); return PT_ERR_INVALID;
+    }
+    if (p->schedule == PT_SCHEDULE_WALK && !((sc->mask & ptd::F_LBVH) && p->max_depth >= 1)) {
+        pt::set_error("render: PT_SCHEDULE_WALK needs a world in the library's LBVH and a bounce limit of at least 1");
+        return PT_ERR_UNSUPPORTED;
     }
     // Refilling keeps waves full but puts their lanes out of phase; that pays when a bounce is
     // mostly the (wave-uniform) closest-hit search, not when shading dominates it.
     ra.refill = (p->schedule == PT_SCHEDULE_REFILL) ||
                 (p->schedule == PT_SCHEDULE_AUTO && ((sc->mask & (ptd::F_LBVH | ptd::F_REFBVH)) || sc->view.n_world > 16));
+    // Measured (MI355X): spheres in the LBVH, 1920x1080: TILES 13.0 ms, REFILL 13.9, WALK 14.4 (shading,
+    // not the search, is most of a bounce there); 2 M triangles in the LBVH, 3840x2160: TILES 31.2,
+    // REFILL 28.2, WALK 18.3 with 48 waiting lanes (32: 21.7, 40: 19.2, 44: 18.5, 52: 18.7).
+    if (p->schedule == PT_SCHEDULE_AUTO && sc->variant >= 0 && sc->variant < 6 && k_masks[sc->variant] == M_SPHERES_LBVH) ra.refill = 0;
+    if (p->schedule == PT_SCHEDULE_WALK ||
+        (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & ptd::F_TRIANGLE) && p->max_depth >= 1)) ra.refill = 2;
+    ra.walk_wait = 48;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
     if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
@@ -627,7 +738,7 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
-        sc->last.schedule = ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
+        sc->last.schedule = ra.refill == 2 ? PT_SCHEDULE_WALK : ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
         sc->last.signature_walk = sc->variant == V_CORNELL_WORLD ? 1 : 0;
     }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;

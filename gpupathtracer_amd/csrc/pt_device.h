@@ -580,50 +580,68 @@ __device__ __forceinline__ bool slab(const float* bmin, const float* bmax, V3 o,
     // widened by a few ulps so a leaf the in-order walk would accept is never pruned
     return tn * 0.9999990f <= tf * 1.0000010f;
 }
+// The walk as a resumable state: begin, then one node or one leaf per step until step() says the
+// walk has ended.  A scheduler that shares one step at a time between the lanes of a wave can
+// stop stepping when too few lanes are still walking and come back later.
+struct LbvhWalk {
+    V3 inv;
+    int cur, sp;
+    float best;
+    int best_id, best_face;
+    bool any;
+};
+__device__ __forceinline__ void lbvh_begin(const SceneView& sv, const Ray& r, float tmax, LbvhWalk& w)
+{
+    w.inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    w.cur = sv.lbvh_root;
+    w.sp = 0;
+    w.any = false;
+    w.best = tmax;
+    w.best_id = -1; w.best_face = 0;
+}
+// one node or one leaf per step: sphere and triangle leaves cost about what a node's two box
+// tests cost, and grouping them by phase (as the reference-tree walk does) measured slower here
+template <uint32_t F>
+__device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, float tmin, float tmax, LbvhWalk& w, int* stack, int* spill)
+{
+    if (w.cur >= 0) {
+        const LbvhNode* n = &sv.lbvh[w.cur];
+        const float lim = sv.lbvh_cull != 0 ? w.best : tmax;
+        float tl, tr;
+        bool hl = slab(n->lmin, n->lmax, r.o, w.inv, tmin, lim, tl);
+        bool hr = slab(n->rmin, n->rmax, r.o, w.inv, tmin, lim, tr);
+        int cl = n->left, cr = n->right;
+        if (hl && hr) {
+            if (tr < tl) { int tmp = cl; cl = cr; cr = tmp; }
+            if (w.sp < LBVH_LDS_STACK) stack[w.sp * 64] = cr;
+            else if (w.sp < LBVH_STACK) spill[w.sp - LBVH_LDS_STACK] = cr;
+            w.sp++;
+            w.cur = cl;
+            return false;
+        } else if (hl) { w.cur = cl; return false; }
+        else if (hr) { w.cur = cr; return false; }
+    } else {
+        const int id = ~w.cur;
+        float t; int face;
+        if (shape_t<F>(sv, id, r, tmin, tmax, t, face)) {
+            if (!w.any || list_order_better(sv, t, id, w.best, w.best_id)) { w.any = true; w.best = t; w.best_id = id; w.best_face = face; }
+        }
+    }
+    if (w.sp == 0) return true;
+    --w.sp;
+    w.cur = (w.sp < LBVH_LDS_STACK) ? stack[w.sp * 64] : spill[w.sp - LBVH_LDS_STACK];
+    return false;
+}
 template <uint32_t F>
 __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float tmin, float tmax,
                                        float& t_out, int& id_out, int& face_out, int* stack)
 {
-    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const bool cull = sv.lbvh_cull != 0;
     int spill[LBVH_STACK - LBVH_LDS_STACK];
-    int sp = 0;
-    int cur = sv.lbvh_root;
-    bool any = false;
-    float best = tmax;
-    int best_id = -1, best_face = 0;
-    // one node or one leaf per turn: sphere and triangle leaves cost about what a node's two box
-    // tests cost, and grouping them by phase (as the reference-tree walk does) measured slower here
-    while (true) {
-        if (cur >= 0) {
-            const LbvhNode* n = &sv.lbvh[cur];
-            const float lim = cull ? best : tmax;
-            float tl, tr;
-            bool hl = slab(n->lmin, n->lmax, r.o, inv, tmin, lim, tl);
-            bool hr = slab(n->rmin, n->rmax, r.o, inv, tmin, lim, tr);
-            int cl = n->left, cr = n->right;
-            if (hl && hr) {
-                if (tr < tl) { int tmp = cl; cl = cr; cr = tmp; }
-                if (sp < LBVH_LDS_STACK) stack[sp * 64] = cr;
-                else if (sp < LBVH_STACK) spill[sp - LBVH_LDS_STACK] = cr;
-                sp++;
-                cur = cl;
-                continue;
-            } else if (hl) { cur = cl; continue; }
-            else if (hr) { cur = cr; continue; }
-        } else {
-            const int id = ~cur;
-            float t; int face;
-            if (shape_t<F>(sv, id, r, tmin, tmax, t, face)) {
-                if (!any || list_order_better(sv, t, id, best, best_id)) { any = true; best = t; best_id = id; best_face = face; }
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        cur = (sp < LBVH_LDS_STACK) ? stack[sp * 64] : spill[sp - LBVH_LDS_STACK];
-    }
-    t_out = best; id_out = best_id; face_out = best_face;
-    return any;
+    LbvhWalk w;
+    lbvh_begin(sv, r, tmax, w);
+    while (!lbvh_step<F>(sv, r, tmin, tmax, w, stack, spill)) {}
+    t_out = w.best; id_out = w.best_id; face_out = w.best_face;
+    return w.any;
 }
 
 // ---- world signatures -------------------------------------------------------------------------------

@@ -17,7 +17,8 @@ struct RenderArgs {
     int32_t n_tiles;               // all tiles of the image
     int32_t sub_x, sub_y;          // 8x8 wave tiles per shard tile
     int32_t n_wave_tiles;          // wave tiles owned by this shard
-    int32_t refill;                // fused scheduler: persistent lanes that pull pixel slots from a counter
+    int32_t refill;                // fused scheduler: 1 persistent lanes that pull pixel slots from a counter, 2 the same with the shared tree walk
+    int32_t walk_wait;             // shared walk: lanes with a finished search that make the wave leave the search loop
     int32_t raw_sum;               // write the plain sample sums instead of sqrt(sum / ns)
     uint64_t seed_offset;          // added to the pixel index before seeding (sample batches; 0 = the reference's stream)
 };

@@ -92,9 +92,14 @@ enum PtPipeline {
 
 /* How the fused scheduler hands pixels to lanes.  The image is the same either way. */
 enum PtSchedule {
-    PT_SCHEDULE_AUTO   = 0, /* REFILL when the closest-hit search dominates (a tree, or > 16 world objects) */
+    PT_SCHEDULE_AUTO   = 0, /* the measured best: WALK for triangles in the LBVH, TILES for spheres in the LBVH and for
+                             * short lists, REFILL for other trees and for lists of more than 16 objects          */
     PT_SCHEDULE_TILES  = 1, /* one 8x8 tile per wave, one pixel per lane                                 */
-    PT_SCHEDULE_REFILL = 2  /* persistent lanes pull the next pixel from a device counter                */
+    PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter                */
+    PT_SCHEDULE_WALK   = 3  /* REFILL, and the wave shares the closest-hit search one tree step at a time:
+                             * lanes whose search has ended shade and start their next search while the
+                             * others keep walking.  Worlds in the library's LBVH (PT_ACCEL_LBVH) with
+                             * max_depth >= 1 only; PT_ERR_UNSUPPORTED otherwise.                          */
 };
 
 /* Ids reported by pt_trace_closest. */

@@ -528,3 +528,44 @@ def test_signature_walk_division_range_edges(oracle):
     np.testing.assert_array_equal(ids_g, ids_o)
     same = (bits(t_g) == bits(t_o)) | (np.isnan(t_g) & np.isnan(t_o))
     assert same.all()
+
+
+@pytest.mark.parametrize("which", ["random", "cornell_spheres", "trimesh", "trimesh_big"])
+def test_shared_walk_schedule_bit_exact(oracle, which):
+    """PT_SCHEDULE_WALK: the wave shares the tree search one step at a time and lanes whose search has
+    ended shade while the others keep walking.  Who steps when never changes what a lane computes:
+    the image is the oracle's, and the image of the other schedules, bit for bit -- including ragged
+    frames (lanes without a pixel), shards, one sample, and the bounce limit reached right after a
+    shade."""
+    if which == "trimesh":
+        d = pt.trimesh_scene(12, 1.0)
+    elif which == "trimesh_big":
+        d = pt.trimesh_scene(60, 1.0)                        # 7 200 triangles: walks of very different lengths
+    else:
+        d = pt.builtin_scene(which, 2.0 if which == "random" else 1.0)
+    d.c.accel = abi.ACCEL_LBVH
+    sc = pt.Scene(d)
+    for nx, ny, ns, depth in ((96, 64, 6, 25), (37, 23, 3, 25), (64, 64, 1, 1), (50, 50, 5, 2)):
+        ref = oracle.render(d, nx, ny, ns, depth)
+        img = sc.render(nx, ny, ns, depth, schedule=abi.SCHEDULE_WALK)
+        assert sc.stats().schedule == abi.SCHEDULE_WALK
+        assert_bit_exact(img, ref, "%s %dx%d ns%d depth%d shared walk" % (which, nx, ny, ns, depth))
+    full = sc.render(100, 60, 4, schedule=abi.SCHEDULE_TILES)
+    acc = np.zeros_like(full)
+    for s in range(3):
+        acc += sc.render(100, 60, 4, shard_index=s, shard_count=3, tile=(8, 8), schedule=abi.SCHEDULE_WALK)
+    assert_bit_exact(acc, full, which + " shards through the shared walk")
+    # AUTO picks it for triangles in the tree, not for spheres
+    sc.render(16, 16, 1)
+    assert (sc.stats().schedule == abi.SCHEDULE_WALK) == which.startswith("trimesh")
+    # a bounce limit of zero has no search to share
+    with pytest.raises(pt.PtError):
+        sc.render(8, 8, 1, 0, schedule=abi.SCHEDULE_WALK)
+    assert_bit_exact(sc.render(8, 8, 2, 0), oracle.render(d, 8, 8, 2, 0), which + " depth 0 under AUTO")
+
+
+def test_shared_walk_needs_the_lbvh():
+    sc = pt.Scene(pt.builtin_scene("cornell", 1.0))
+    with pytest.raises(pt.PtError) as e:
+        sc.render(8, 8, 1, schedule=abi.SCHEDULE_WALK)
+    assert e.value.code == abi.ERR_UNSUPPORTED

@@ -19,7 +19,7 @@
         for (int i = 0; i < ITERS; i++) {                                                            \
             asm volatile(ASM8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), \
                                 "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)                               \
-                              : "v"(b), "v"(c), "v"(e) : "vcc");                                     \
+                              : "v"(b), "v"(c), "v"(e) : "vcc", "s2", "s3", "s4", "s10", "s11");                                     \
         }                                                                                            \
         unsigned long long t1 = __builtin_amdgcn_s_memtime();                                        \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3); \
@@ -63,6 +63,30 @@ PROBE_KERNEL(k_mul_f64, REP8(D4_2("v_mul_f64") D4_2("v_mul_f64")))
 PROBE_KERNEL(k_add_f64, REP8(D4_2("v_add_f64") D4_2("v_add_f64")))
 PROBE_KERNEL(k_cvt_f64_f32, REP8("v_cvt_f64_f32 %8, %0\nv_cvt_f64_f32 %9, %1\nv_cvt_f64_f32 %10, %2\nv_cvt_f64_f32 %11, %3\nv_cvt_f64_f32 %8, %4\nv_cvt_f64_f32 %9, %5\nv_cvt_f64_f32 %10, %6\nv_cvt_f64_f32 %11, %7\n"))
 PROBE_KERNEL(k_cvt_f32_f64, REP8("v_cvt_f32_f64 %0, %8\nv_cvt_f32_f64 %1, %9\nv_cvt_f32_f64 %2, %10\nv_cvt_f32_f64 %3, %11\nv_cvt_f32_f64 %4, %8\nv_cvt_f32_f64 %5, %9\nv_cvt_f32_f64 %6, %10\nv_cvt_f32_f64 %7, %11\n"))
+PROBE_KERNEL(k_cndmask_sgpr, REP8(I8("v_cndmask_b32", ", %12, s[2:3]")))
+PROBE_KERNEL(k_cmp_sgpr, REP8("v_cmp_lt_f32 s[10:11], %0, %12\nv_cmp_lt_f32 s[10:11], %1, %12\nv_cmp_lt_f32 s[10:11], %2, %12\nv_cmp_lt_f32 s[10:11], %3, %12\nv_cmp_lt_f32 s[10:11], %4, %12\nv_cmp_lt_f32 s[10:11], %5, %12\nv_cmp_lt_f32 s[10:11], %6, %12\nv_cmp_lt_f32 s[10:11], %7, %12\n"))
+PROBE_KERNEL(k_cmp_cnd_pair, REP8("v_cmp_lt_f32 vcc, %0, %12\nv_cndmask_b32 %1, %1, %12, vcc\nv_cmp_lt_f32 vcc, %2, %12\nv_cndmask_b32 %3, %3, %12, vcc\nv_cmp_lt_f32 vcc, %4, %12\nv_cndmask_b32 %5, %5, %12, vcc\nv_cmp_lt_f32 vcc, %6, %12\nv_cndmask_b32 %7, %7, %12, vcc\n"))
+PROBE_KERNEL(k_min3_f32, REP8(I8_3("v_min3_f32")))
+PROBE_KERNEL(k_med3_f32, REP8(I8_3("v_med3_f32")))
+PROBE_KERNEL(k_min_f32, REP8(I8("v_min_f32", ", %12")))
+PROBE_KERNEL(k_xor_b32, REP8(I8("v_xor_b32", ", %12")))
+PROBE_KERNEL(k_or_b32, REP8(I8("v_or_b32", ", %12")))
+PROBE_KERNEL(k_sub_f32, REP8(I8("v_sub_f32", ", %12")))
+PROBE_KERNEL(k_fmac_f32, REP8(I8("v_fmac_f32", ", %12")))
+PROBE_KERNEL(k_mul_f32_abs, REP8("v_mul_f32 %0, |%0|, %12\nv_mul_f32 %1, |%1|, %12\nv_mul_f32 %2, |%2|, %12\nv_mul_f32 %3, |%3|, %12\nv_mul_f32 %4, |%4|, %12\nv_mul_f32 %5, |%5|, %12\nv_mul_f32 %6, |%6|, %12\nv_mul_f32 %7, |%7|, %12\n"))
+PROBE_KERNEL(k_mul_f32_sgpr, REP8("v_mul_f32 %0, s4, %0\nv_mul_f32 %1, s4, %1\nv_mul_f32 %2, s4, %2\nv_mul_f32 %3, s4, %3\nv_mul_f32 %4, s4, %4\nv_mul_f32 %5, s4, %5\nv_mul_f32 %6, s4, %6\nv_mul_f32 %7, s4, %7\n"))
+PROBE_KERNEL(k_mul_f32_lit, REP8("v_mul_f32 %0, 0x3f8ccccd, %0\nv_mul_f32 %1, 0x3f8ccccd, %1\nv_mul_f32 %2, 0x3f8ccccd, %2\nv_mul_f32 %3, 0x3f8ccccd, %3\nv_mul_f32 %4, 0x3f8ccccd, %4\nv_mul_f32 %5, 0x3f8ccccd, %5\nv_mul_f32 %6, 0x3f8ccccd, %6\nv_mul_f32 %7, 0x3f8ccccd, %7\n"))
+PROBE_KERNEL(k_fma_f32_sgpr, REP8("v_fma_f32 %0, %0, s4, %13\nv_fma_f32 %1, %1, s4, %13\nv_fma_f32 %2, %2, s4, %13\nv_fma_f32 %3, %3, s4, %13\nv_fma_f32 %4, %4, s4, %13\nv_fma_f32 %5, %5, s4, %13\nv_fma_f32 %6, %6, s4, %13\nv_fma_f32 %7, %7, s4, %13\n"))
+PROBE_KERNEL(k_alignbit, REP8(I8_3("v_alignbit_b32")))
+PROBE_KERNEL(k_lshrrev_b32, REP8(I8("v_lshrrev_b32", ", 3")))
+PROBE_KERNEL(k_lshrrev_b64, REP8("v_lshrrev_b64 %8, 3, %8\nv_lshrrev_b64 %9, 3, %9\nv_lshrrev_b64 %10, 3, %10\nv_lshrrev_b64 %11, 3, %11\nv_lshrrev_b64 %8, 3, %8\nv_lshrrev_b64 %9, 3, %9\nv_lshrrev_b64 %10, 3, %10\nv_lshrrev_b64 %11, 3, %11\n"))
+PROBE_KERNEL(k_cvt_f32_u32, REP8(I8("v_cvt_f32_u32", "")))
+PROBE_KERNEL(k_add3_u32, REP8(I8_3("v_add3_u32")))
+PROBE_KERNEL(k_lshl_add_u32, REP8(I8_3("v_lshl_add_u32")))
+PROBE_KERNEL(k_add_co_u32, REP8("v_add_co_u32 %0, vcc, %0, %12\nv_add_co_u32 %1, vcc, %1, %12\nv_add_co_u32 %2, vcc, %2, %12\nv_add_co_u32 %3, vcc, %3, %12\nv_add_co_u32 %4, vcc, %4, %12\nv_add_co_u32 %5, vcc, %5, %12\nv_add_co_u32 %6, vcc, %6, %12\nv_add_co_u32 %7, vcc, %7, %12\n"))
+PROBE_KERNEL(k_mov_b64, REP8("v_mov_b64 %8, %14\nv_mov_b64 %9, %14\nv_mov_b64 %10, %14\nv_mov_b64 %11, %14\nv_mov_b64 %8, %14\nv_mov_b64 %9, %14\nv_mov_b64 %10, %14\nv_mov_b64 %11, %14\n"))
+PROBE_KERNEL(k_ldexp_f32, REP8(I8("v_ldexp_f32", ", %12")))
+PROBE_KERNEL(k_cmp_class, REP8("v_cmp_class_f32 vcc, %0, %12\nv_cmp_class_f32 vcc, %1, %12\nv_cmp_class_f32 vcc, %2, %12\nv_cmp_class_f32 vcc, %3, %12\nv_cmp_class_f32 vcc, %4, %12\nv_cmp_class_f32 vcc, %5, %12\nv_cmp_class_f32 vcc, %6, %12\nv_cmp_class_f32 vcc, %7, %12\n"))
 // dependent chain: every instruction reads the previous one's result
 PROBE_KERNEL(k_fma_f32_dep, REP8("v_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\nv_fma_f32 %0, %0, %12, %13\n"))
 PROBE_KERNEL(k_mad_u64_u32, REP8("v_mad_u64_u32 %8, vcc, %0, %12, %8\nv_mad_u64_u32 %9, vcc, %1, %12, %9\nv_mad_u64_u32 %10, vcc, %2, %12, %10\nv_mad_u64_u32 %11, vcc, %3, %12, %11\nv_mad_u64_u32 %8, vcc, %4, %12, %8\nv_mad_u64_u32 %9, vcc, %5, %12, %9\nv_mad_u64_u32 %10, vcc, %6, %12, %10\nv_mad_u64_u32 %11, vcc, %7, %12, %11\n"))
@@ -80,6 +104,12 @@ int main()
         {"v_div_scale_f32", k_div_scale}, {"v_div_fmas_f32", k_div_fmas}, {"v_div_fixup_f32", k_div_fixup},
         {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64},
         {"v_add_f64", k_add_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_f64", k_cvt_f32_f64},
+        {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr}, {"v_cmp_lt_f32 (sgpr dst)", k_cmp_sgpr}, {"v_cmp + v_cndmask pairs", k_cmp_cnd_pair},
+        {"v_min3_f32", k_min3_f32}, {"v_med3_f32", k_med3_f32}, {"v_min_f32", k_min_f32}, {"v_xor_b32", k_xor_b32}, {"v_or_b32", k_or_b32},
+        {"v_sub_f32", k_sub_f32}, {"v_fmac_f32", k_fmac_f32}, {"v_mul_f32 |abs|", k_mul_f32_abs}, {"v_mul_f32 sgpr", k_mul_f32_sgpr},
+        {"v_mul_f32 literal", k_mul_f32_lit}, {"v_fma_f32 sgpr", k_fma_f32_sgpr}, {"v_alignbit_b32", k_alignbit}, {"v_lshrrev_b32", k_lshrrev_b32},
+        {"v_lshrrev_b64", k_lshrrev_b64}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_add3_u32", k_add3_u32}, {"v_lshl_add_u32", k_lshl_add_u32},
+        {"v_add_co_u32", k_add_co_u32}, {"v_mov_b64", k_mov_b64}, {"v_ldexp_f32", k_ldexp_f32}, {"v_cmp_class_f32", k_cmp_class},
     };
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { printf("no device\n"); return 1; }
