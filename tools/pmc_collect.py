@@ -49,7 +49,7 @@ def main():
     s = sums
     der = {"launches_summed": launches}
     if "SQ_INSTS_VALU" in s and "SQ_THREAD_CYCLES_VALU" in s:
-        der["valu_lane_utilisation"] = s["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * s["SQ_ACTIVE_INST_VALU"]) if s.get("SQ_ACTIVE_INST_VALU") else None
+        der["valu_lane_utilisation"] = s["SQ_THREAD_CYCLES_VALU"] / (64.0 * s["SQ_ACTIVE_INST_VALU"]) if s.get("SQ_ACTIVE_INST_VALU") else None
     if "SQ_WAVE_CYCLES" in s:
         der["wave_cycles_waiting_on_waitcnt_frac"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"]
         der["wave_cycles_waiting_to_issue_frac"] = s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]
@@ -61,6 +61,10 @@ def main():
                 der["valu_active_quads_per_simd_quad"] = s["SQ_ACTIVE_INST_VALU"] / simd_quads
             if "SQ_INSTS_VALU" in s:
                 der["cycles_per_valu_inst_per_simd"] = simd_quads * 4.0 / s["SQ_INSTS_VALU"]
+    if "FETCH_SIZE" in s:          # rocprofv3 reports KiB; on gfx950 the fetch counter reads half the bytes moved
+        der["fetch_bytes_per_launch_corrected_x2"] = s["FETCH_SIZE"] * 1024.0 * 2.0 / max(1, launches)
+    if "WRITE_SIZE" in s:
+        der["write_kib_per_launch"] = s["WRITE_SIZE"] / max(1, launches)
     s["_derived"] = der
     s["_command"] = " ".join(cmd)
     s["_kernel_substring"] = needle
