@@ -349,7 +349,8 @@ int pick_variant(uint32_t scene_mask)
     case 3: LAUNCH(M_TRIMESH, AnyWorld); break;               \
     case 4: LAUNCH(M_ALL, AnyWorld); break;                   \
     case 5: LAUNCH(M_ALL_LBVH, AnyWorld); break;              \
-    default: LAUNCH(M_CORNELL, CornellWorld); break;          \
+    case 6: LAUNCH(M_CORNELL, CornellWorld); break;           \
+    default: LAUNCH(M_CORNELL, Branchless<CornellWorld>); break; \
     }
 
 template <uint32_t F>
@@ -423,6 +424,26 @@ bool world_matches(const PtSceneDesc* d, WorldSig<K...>)
     for (int i = 0; i < d->n_world; i++)
         if (world_kind(d, i) != kinds[i]) return false;
     return true;
+}
+
+// The signature walk's constants, one slot per world entry (layout: world_entry in pt_device.h).
+std::vector<float> signature_table(const PtSceneDesc* d)
+{
+    std::vector<float> t((size_t)d->n_world * ptd::SIG_SLOT, 0.0f);
+    for (int i = 0; i < d->n_world; i++) {
+        const int id = d->world[i].index;
+        const PtShape& s = d->shapes[id];
+        float* q = &t[(size_t)i * ptd::SIG_SLOT];
+        for (int j = 0; j < 6; j++) q[j] = s.p[j];
+        if (world_kind(d, i) == WK_BOX_TR) {
+            const PtXform& tr = d->xforms[s.xform_first];
+            const PtXform& ro = d->xforms[s.xform_first + 1];
+            q[6] = tr.v[0]; q[7] = tr.v[1]; q[8] = tr.v[2];
+            q[9] = ro.v[0]; q[10] = ro.v[1];
+        }
+        std::memcpy(&q[ptd::SIG_SLOT - 1], &id, sizeof id);
+    }
+    return t;
 }
 
 }  // namespace
@@ -607,6 +628,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     std::memcpy(v.ambient, desc->ambient_color, sizeof v.ambient);
     std::memcpy(v.camera, desc->camera, sizeof v.camera);
     v.lbvh = nullptr; v.lbvh_root = 0; v.lbvh_cull = 0;
+    v.sig = nullptr;
     sc->n_shapes = desc->n_shapes;
     sc->n_media = desc->n_media;
 
@@ -626,7 +648,11 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     }
     sc->mask = mask;
     sc->variant = pick_variant(mask);
-    if (sc->variant == 0 && world_matches(desc, CornellWorld{})) sc->variant = V_CORNELL_WORLD;
+    if (sc->variant == 0 && world_matches(desc, CornellWorld{})) {
+        const std::vector<float> table = signature_table(desc);
+        if (!upload(sc, table.data(), table.size(), &v.sig, "upload signature table")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+        sc->variant = V_CORNELL_WORLD;
+    }
     if (sc->variant < 0) { pt::set_error("pt_scene_create: no kernel specialisation covers this scene"); pt_scene_destroy(sc); return PT_ERR_UNSUPPORTED; }
     {
         void* ctr = nullptr;
@@ -691,6 +717,20 @@ static uint64_t owned_pixels(const PtRenderParams* p, const RenderArgs& ra)
     return owned_px;
 }
 
+namespace {
+// The signature walk comes with and without control flow between its tests.  Without, the walk is
+// one scheduling block whose loads and divisions overlap: faster when a SIMD holds few waves to
+// switch to, slightly slower (more selects) when it holds many.  Measured on an MI355X (1024 SIMDs),
+// Cornell 1024^2 at 512 spp, with / without control flow: whole frame 47.7 / 48.6 ms, half 28.6 / 28.4,
+// a quarter 19.7 / 19.2, an eighth 15.1 / 14.2: the two meet at eight wave tiles per SIMD.
+constexpr int FLAT_UP_TO_WAVES = 8 * 1024;
+int launch_variant(const PtScene* sc, const RenderArgs& ra)
+{
+    if (sc->variant != V_CORNELL_WORLD) return sc->variant;
+    return ra.n_wave_tiles <= FLAT_UP_TO_WAVES ? V_CORNELL_WORLD_FLAT : V_CORNELL_WORLD;
+}
+}  // namespace
+
 extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream)
 {
     if (!sc || !p || !d_out_rgb) { pt::set_error("pt_render_device: null argument"); return PT_ERR_INVALID; }
@@ -734,7 +774,7 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
         sc->last.pipeline = PT_PIPELINE_WAVEFRONT;
     } else {
         if (!hip_ok(hipMemsetAsync(sc->next_slot, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
-        if (ra.n_wave_tiles > 0) launch_render(sc->variant, sc->view, ra, out, sc->next_slot, st);
+        if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, sc->next_slot, st);
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
@@ -790,7 +830,7 @@ extern "C" int pt_render_pass(PtScene* sc, const PtRenderParams* p, void* d_accu
         !hip_ok(hipMemsetAsync(d_accum, 0, pt_accum_bytes(p->nx, p->ny), st), "hipMemsetAsync(accumulators)")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->last = PtRenderStats{};
-    if (ra.n_wave_tiles > 0) launch_pass(sc->variant, sc->view, ra, static_cast<PtAccumPixel*>(d_accum), first_sample, out, st);
+    if (ra.n_wave_tiles > 0) launch_pass(launch_variant(sc, ra), sc->view, ra, static_cast<PtAccumPixel*>(d_accum), first_sample, out, st);
     if (!hip_ok(hipGetLastError(), "render pass launch")) return PT_ERR_HIP;
     sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
     sc->last.pipeline = PT_PIPELINE_FUSED;
@@ -911,7 +951,9 @@ extern "C" int pt_trace_closest(PtScene* sc, const PtRay* rays, size_t n, int32_
         !hip_ok(hipMalloc((void**)&d_t, n * sizeof(float)), "hipMalloc(t)")) rc = PT_ERR_OOM;
     if (rc == PT_OK && !hip_ok(hipMemcpy(d_rays, rays, n * sizeof(PtRay), hipMemcpyHostToDevice), "hipMemcpy(rays)")) rc = PT_ERR_HIP;
     if (rc == PT_OK) {
-        launch_trace(sc->variant, sc->view, d_rays, n, d_ids, d_t, nullptr);
+        int variant = sc->variant;                      // the same rule as launch_variant, in waves of rays
+        if (variant == V_CORNELL_WORLD && (n + 63) / 64 <= (size_t)FLAT_UP_TO_WAVES) variant = V_CORNELL_WORLD_FLAT;
+        launch_trace(variant, sc->view, d_rays, n, d_ids, d_t, nullptr);
         if (!hip_ok(hipGetLastError(), "trace kernel launch") || !hip_ok(hipStreamSynchronize(nullptr), "trace (synchronize)")) rc = PT_ERR_HIP;
     }
     if (rc == PT_OK && (!hip_ok(hipMemcpy(prim_id, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy(ids)") ||

@@ -70,6 +70,7 @@ struct SceneView {
     const PtObject*   world;
     const int32_t*    lights;
     const LbvhNode*   lbvh;
+    const float*      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
     int32_t n_world, n_lights, lights_is_list, ambient_type;
     int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
     int32_t lbvh_cull;          // 1: prune by distance (no triangles in the tree)
@@ -284,6 +285,35 @@ __device__ __forceinline__ bool rect_t(float ok, const D& dk, float oa, float da
     if (a < a0 || a > a1 || b < b0 || b > b1) return false;
     t = tt;
     return true;
+}
+// The same test without control flow, for the straight-line signature walk: all of it is
+// evaluated and the verdict is one boolean (the comparisons are rect_t's, so NaN behaves alike).
+// With no branches between the entries of a list the compiler schedules the whole walk as one
+// block: the entries' constants are loaded ahead of their use and the tests overlap.
+template <class D>
+__device__ __forceinline__ bool rect_ok(float ok, const D& dk, float oa, float da, float ob, float db,
+                                        float a0, float a1, float b0, float b1, float k,
+                                        float t0, float t1, float& tt)
+{
+    tt = quot(k - ok, dk);
+    const float a = oa + tt * da;
+    const float b = ob + tt * db;
+    const bool out_t = (tt < t0) | (tt > t1);
+    const bool out_ab = (a < a0) | (a > a1) | (b < b0) | (b > b1);
+    return !(out_t | out_ab);
+}
+template <class D>
+__device__ __forceinline__ void box_sel(const float* q, const Ray& r, const D& dx, const D& dy, const D& dz,
+                                        float t0, float& closest, int& code, int base)
+{
+    const float x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
+    float tt;
+    if (rect_ok(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z1, t0, closest, tt)) { closest = tt; code = base + 0; }
+    if (rect_ok(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z0, t0, closest, tt)) { closest = tt; code = base + 1; }
+    if (rect_ok(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y1, t0, closest, tt)) { closest = tt; code = base + 2; }
+    if (rect_ok(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y0, t0, closest, tt)) { closest = tt; code = base + 3; }
+    if (rect_ok(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x1, t0, closest, tt)) { closest = tt; code = base + 4; }
+    if (rect_ok(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x0, t0, closest, tt)) { closest = tt; code = base + 5; }
 }
 // Box = list of six rectangles searched with a shrinking upper bound
 // (include/ptRectangle.h:199-217, src/ptHitableList.cu:12-27): a later face wins ties.
@@ -655,26 +685,66 @@ __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float 
 enum : int { WK_RECT_XY = 1, WK_RECT_XZ = 2, WK_RECT_YZ = 3, WK_BOX_TR = 4, WK_SPHERE = 5 };
 struct AnyWorld {};                                        // any list: the generic walk
 template <int... K> struct WorldSig { static constexpr int count = (int)sizeof...(K); };
+// The same signature walked without control flow between the tests (rect_ok): a little more
+// vector work per test, but one scheduling block, which pays when few waves share a SIMD.
+template <class Sig> struct Branchless : Sig {};
+template <class W> struct is_branchless { static constexpr bool value = false; };
+template <class Sig> struct is_branchless<Branchless<Sig>> { static constexpr bool value = true; };
 // cornell_box (src/ptMain.cu:286-317): five walls and the lamp, then the two Translate(RotateY(Box))
 using CornellWorld = WorldSig<WK_RECT_YZ, WK_RECT_YZ, WK_RECT_XZ, WK_RECT_XZ, WK_RECT_XZ, WK_RECT_XY, WK_BOX_TR, WK_BOX_TR>;
 
-template <uint32_t F, int KIND, bool TAME, class D>
+// The entries' constants are read from a flat table built when the signature is matched: one
+// SIG_SLOT-float slot per world entry at a constant offset from one base, so every load of the
+// walk is independent of every other (the scene tables would be reached through world[k].index ->
+// shape -> wrapper list, three dependent scalar loads per entry that no other work of the wave
+// can cover).  Slot layout: rectangle a0, a1, b0, b1, k; sphere centre, radius; wrapped box
+// pmin, pmax, translation, sin, cos; last word the shape index.
+constexpr int SIG_SLOT = 16;
+template <uint32_t F, int KIND, bool TAME, bool FLAT, class D>
 __device__ __forceinline__ void world_entry(const SceneView& sv, int k, const Ray& r, const D& dx, const D& dy, const D& dz,
-                                            float tmin, float& closest, bool& any, Hit& h)
+                                            float tmin, float& closest, int& code)
 {
-    const int id = sv.world[k].index;
-    const PtShape* s = &sv.shapes[id];
-    float t = 0; int face = 0;
-    bool hit = false;
-    if (KIND == WK_RECT_XY) hit = rect_t(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
-    if (KIND == WK_RECT_XZ) hit = rect_t(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
-    if (KIND == WK_RECT_YZ) hit = rect_t(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, s->p[0], s->p[1], s->p[2], s->p[3], s->p[4], tmin, closest, t);
-    if (KIND == WK_SPHERE) hit = sphere_t(mk(s->p[0], s->p[1], s->p[2]), s->p[3], r, tmin, closest, t);
+    // `code` = 8 * entry + face of the nearest accepted test so far (-1: none).  A box's faces are
+    // tested against the list's own shrinking bound: the box's inner list starts from that bound and
+    // the list takes the box's answer whenever there is one, so the flattened walk accepts the
+    // same tests in the same order (include/ptRectangle.h:199-217, src/ptHitableList.cu:12-27).
+    const float* q = sv.sig + SIG_SLOT * k;
+    float t;
+    if constexpr (!FLAT) {
+        int face = 0;
+        bool hit = false;
+        if (KIND == WK_RECT_XY) hit = rect_t(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, q[0], q[1], q[2], q[3], q[4], tmin, closest, t);
+        if (KIND == WK_RECT_XZ) hit = rect_t(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, q[0], q[1], q[2], q[3], q[4], tmin, closest, t);
+        if (KIND == WK_RECT_YZ) hit = rect_t(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, q[0], q[1], q[2], q[3], q[4], tmin, closest, t);
+        if (KIND == WK_SPHERE) hit = sphere_t(mk(q[0], q[1], q[2]), q[3], r, tmin, closest, t);
+        if (KIND == WK_BOX_TR) {
+            Ray lr = r;
+            lr.o = lr.o - mk(q[6], q[7], q[8]);
+            const float sinT = q[9], cosT = q[10];
+            const float ox = cosT * lr.o.x - sinT * lr.o.z;
+            const float oz = sinT * lr.o.x + cosT * lr.o.z;
+            const float ldx = cosT * lr.d.x - sinT * lr.d.z;
+            const float ldz = sinT * lr.d.x + cosT * lr.d.z;
+            lr.o.x = ox; lr.o.z = oz; lr.d.x = ldx; lr.d.z = ldz;
+            if constexpr (TAME) {
+                const bool tame = fabsf(lr.o.x) + fabsf(lr.o.y) + fabsf(lr.o.z) <= RCP_BIG && fabsf(ldx) >= RCP_D_MIN && fabsf(ldz) >= RCP_D_MIN;
+                if (tame) hit = box_t(q, lr, rcp_refined(ldx), dy, rcp_refined(ldz), tmin, closest, t, face);
+                else hit = box_t(q, lr, tmin, closest, t, face);
+            } else {
+                hit = box_t(q, lr, tmin, closest, t, face);
+            }
+        }
+        if (hit) { closest = t; code = 8 * k + face; }
+        return;
+    }
+    if (KIND == WK_RECT_XY) { if (rect_ok(r.o.z, dz, r.o.x, r.d.x, r.o.y, r.d.y, q[0], q[1], q[2], q[3], q[4], tmin, closest, t)) { closest = t; code = 8 * k; } }
+    if (KIND == WK_RECT_XZ) { if (rect_ok(r.o.y, dy, r.o.x, r.d.x, r.o.z, r.d.z, q[0], q[1], q[2], q[3], q[4], tmin, closest, t)) { closest = t; code = 8 * k; } }
+    if (KIND == WK_RECT_YZ) { if (rect_ok(r.o.x, dx, r.o.y, r.d.y, r.o.z, r.d.z, q[0], q[1], q[2], q[3], q[4], tmin, closest, t)) { closest = t; code = 8 * k; } }
+    if (KIND == WK_SPHERE) { if (sphere_t(mk(q[0], q[1], q[2]), q[3], r, tmin, closest, t)) { closest = t; code = 8 * k; } }
     if (KIND == WK_BOX_TR) {                               // Translate(RotateY(Box)): to_local's arithmetic, written out
-        const PtXform tr = sv.xforms[s->xform_first], ro = sv.xforms[s->xform_first + 1];
         Ray lr = r;
-        lr.o = lr.o - mk(tr.v[0], tr.v[1], tr.v[2]);
-        const float sinT = ro.v[0], cosT = ro.v[1];
+        lr.o = lr.o - mk(q[6], q[7], q[8]);
+        const float sinT = q[9], cosT = q[10];
         const float ox = cosT * lr.o.x - sinT * lr.o.z;
         const float oz = sinT * lr.o.x + cosT * lr.o.z;
         const float ldx = cosT * lr.d.x - sinT * lr.d.z;
@@ -684,34 +754,37 @@ __device__ __forceinline__ void world_entry(const SceneView& sv, int k, const Ra
             // the rotation keeps d.y (shared reciprocal) and at most doubles magnitudes; what is left
             // to test is that the turned components did not cancel and that the local origin is tame
             const bool tame = fabsf(lr.o.x) + fabsf(lr.o.y) + fabsf(lr.o.z) <= RCP_BIG && fabsf(ldx) >= RCP_D_MIN && fabsf(ldz) >= RCP_D_MIN;
-            if (tame) hit = box_t(s->p, lr, rcp_refined(ldx), dy, rcp_refined(ldz), tmin, closest, t, face);
-            else hit = box_t(s->p, lr, tmin, closest, t, face);
+            if (tame) box_sel(q, lr, rcp_refined(ldx), dy, rcp_refined(ldz), tmin, closest, code, 8 * k);
+            else box_sel(q, lr, lr.d.x, lr.d.y, lr.d.z, tmin, closest, code, 8 * k);
         } else {
-            hit = box_t(s->p, lr, tmin, closest, t, face);
+            box_sel(q, lr, lr.d.x, lr.d.y, lr.d.z, tmin, closest, code, 8 * k);
         }
     }
-    if (hit) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
 }
 // Rays whose origin and direction components lie in the range where the shortened division is
 // the whole division (see rcp_refined) take it, with one reciprocal per axis; any other ray
 // (an axis-parallel direction, an overflowing origin, NaN) takes the compiler's full sequence.
 // The scene's own constants are range-checked when the signature is matched on the host.
-template <uint32_t F, int... K>
+template <uint32_t F, bool FLAT, int... K>
 __device__ __forceinline__ bool world_hit_sig(const SceneView& sv, const Ray& r, float tmin, float tmax, Hit& h, WorldSig<K...>)
 {
-    bool any = false;
     float closest = tmax;
+    int code = -1;
     int k = 0;
     const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
     const bool tame = tmin >= RCP_TMIN_MIN && fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) <= RCP_BIG && ax + ay + az <= RCP_BIG &&
                       ax >= RCP_D_MIN && ay >= RCP_D_MIN && az >= RCP_D_MIN;
     if (tame) {
         const Rcp cx = rcp_refined(r.d.x), cy = rcp_refined(r.d.y), cz = rcp_refined(r.d.z);
-        ((world_entry<F, K, true>(sv, k++, r, cx, cy, cz, tmin, closest, any, h)), ...);
+        ((world_entry<F, K, true, FLAT>(sv, k++, r, cx, cy, cz, tmin, closest, code)), ...);
     } else {
-        ((world_entry<F, K, false>(sv, k++, r, r.d.x, r.d.y, r.d.z, tmin, closest, any, h)), ...);
+        ((world_entry<F, K, false, FLAT>(sv, k++, r, r.d.x, r.d.y, r.d.z, tmin, closest, code)), ...);
     }
-    return any;
+    if (code < 0) return false;
+    h.t = closest;
+    h.id = __float_as_int(sv.sig[SIG_SLOT * (code >> 3) + SIG_SLOT - 1]);
+    h.face = code & 7;
+    return true;
 }
 template <class W> struct is_any_world { static constexpr bool value = false; };
 template <> struct is_any_world<AnyWorld> { static constexpr bool value = true; };
@@ -724,7 +797,7 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
 {
     h.id = PT_ID_MISS; h.face = 0; h.t = tmax; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
     if constexpr (!is_any_world<W>::value) {
-        return world_hit_sig<F>(sv, r, tmin, tmax, h, W{});
+        return world_hit_sig<F, is_branchless<W>::value>(sv, r, tmin, tmax, h, W{});
     }
     if (F & F_LBVH) {
         float t; int id, face;

@@ -49,7 +49,8 @@ constexpr uint32_t M_TRIMESH = F_RECT | F_TRIANGLE | F_LIGHTS | F_LBVH;
 constexpr uint32_t M_ALL = F_ALL & ~F_LBVH;
 constexpr uint32_t M_ALL_LBVH = F_ALL;
 
-constexpr int N_VARIANTS = 7;
+constexpr int N_VARIANTS = 8;
+constexpr int V_CORNELL_WORLD_FLAT = 7;   // the same walk without control flow (launches that leave few waves per SIMD)
 constexpr int V_CORNELL_WORLD = 6;    // M_CORNELL with the CornellWorld signature walk (the fused kernels and the closest-hit kernel)
 }  // namespace ptk
 
