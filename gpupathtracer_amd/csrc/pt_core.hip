@@ -59,12 +59,14 @@ __device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs
 
 // One bounce of the pixel's sample loop.  Returns true when the pixel's last sample has ended.
 template <uint32_t F, class W>
-__device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, float fnx, float fny,
+__device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, const Rcp& fnx, const Rcp& fny,
                                           int* my_stack)
 {
     if (st.fresh) {                                       // render_pixel, src/ptMain.cu:158-160
-        float u = ((float)st.x + st.rng.rand()) / fnx;
-        float v = ((float)st.y + st.rng.rand()) / fny;
+        // (x + rand) / nx: the numerator is 0 or at least 2^-32 and the frame size at most 2^31, inside
+        // the range where the shortened division is the whole division (rcp_refined, pt_device.h)
+        float u = quot((float)st.x + st.rng.rand(), fnx);
+        float v = quot((float)st.y + st.rng.rand(), fny);
         st.ray = camera_ray(sv, u, v, st.rng);
         st.thr = mk(1, 1, 1);
         st.depth = 0;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(Scene
     int x, ytop;
     if (!wave_pixel(ra, wave, lane, x, ytop)) return;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
     LaneState st;
     lane_init(st);
     unsigned i;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
     int x, ytop;
     if (!wave_pixel(ra, wave, lane, x, ytop)) return;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
     LaneState st;
     lane_init(st);
     unsigned i;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
     const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
-    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
     LaneState st;
     lane_init(st);
     unsigned i = 0;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane];
     const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
-    const float fnx = (float)ra.nx, fny = (float)ra.ny;
+    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
     enum { NEED_PIXEL, NEXT_RAY, WALKING, WALKED, DONE };
     LaneState st;
     lane_init(st);
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
         }
         if (mode == NEXT_RAY) {
             if (st.fresh) {                                   // render_pixel, src/ptMain.cu:158-160
-                float u = ((float)st.x + st.rng.rand()) / fnx;
-                float v = ((float)st.y + st.rng.rand()) / fny;
+                float u = quot((float)st.x + st.rng.rand(), fnx);
+                float v = quot((float)st.y + st.rng.rand(), fny);
                 st.ray = camera_ray(sv, u, v, st.rng);
                 st.thr = mk(1, 1, 1);
                 st.depth = 0;

@@ -143,10 +143,8 @@ __device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
     ptm::sincosf_glibc(theta, &sn, &cs);
     return mk(r * cs, r * sn, 0.0f);
 }
-__device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
+__device__ __forceinline__ V3 random_cosine_direction(float r1, float r2)
 {
-    float r1 = g.rand();
-    float r2 = g.rand();
     float z = sqrtf(1 - r2);
     float phi = 2 * PI_F * r1;
     float sn, cs;
@@ -154,6 +152,12 @@ __device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
     float x = cs * 2 * sqrtf(r2);
     float y = sn * 2 * sqrtf(r2);
     return mk(x, y, z);
+}
+__device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
+{
+    float r1 = g.rand();
+    float r2 = g.rand();
+    return random_cosine_direction(r1, r2);
 }
 __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqrd, Pcg& g)
 {
@@ -1205,7 +1209,21 @@ __device__ __forceinline__ bool shade(const SceneView& sv, Ray& ray, const Hit& 
     Onb uvw = onb_from_w(sf.n);
     V3 dir; float pdf_value;
     if ((F & F_LIGHTS) && sv.n_lights > 0) {
-        if (g.rand() < 0.5f) dir = lights_random<F>(sv, sf.p, g);   // MixturePdf::generate, include/ptPDF.h:94-100
+        if (!(F & F_LIGHT_MISC)) {
+            // One bare XZ rectangle as the light: either side of the mixture draws two numbers, so
+            // they are drawn before the choice is acted on (one copy of the generator's code for the
+            // wave instead of one per side); z then x for the rectangle, r1 then r2 for the cosine lobe.
+            const bool pick_light = g.rand() < 0.5f;                // MixturePdf::generate, include/ptPDF.h:94-100
+            const float d1 = g.rand();
+            const float d2 = g.rand();
+            if (pick_light) {                                       // include/ptRectangle.h:91-95
+                const PtShape* ls = &sv.shapes[sv.lights[0]];
+                V3 rp = mk(ls->p[0] + d2 * (ls->p[1] - ls->p[0]), ls->p[4], ls->p[2] + d1 * (ls->p[3] - ls->p[2]));
+                dir = rp - sf.p;
+            } else {
+                dir = onb_local(uvw, random_cosine_direction(d1, d2));
+            }
+        } else if (g.rand() < 0.5f) dir = lights_random<F>(sv, sf.p, g);
         else dir = onb_local(uvw, random_cosine_direction(g));
         pdf_value = 0.5f * lights_pdf<F>(sv, sf.p, dir) + 0.5f * cosine_pdf_value(uvw, dir);
     } else {
