@@ -53,6 +53,9 @@ def main():
         res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1, **kw))
     if a.only in ("", "c3"):
         res.append(run("C3 final 1920x1080", pt.builtin_scene("final", 16 / 9), 1920, 1080, 256 // q, **kw))
+    if a.only in ("", "c3lbvh"):
+        res.append(run("C3 final 1920x1080, boxes of the reference BVH in the library's LBVH", pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH),
+                       1920, 1080, 256 // q, **kw))
     if a.only in ("", "c4"):
         d = pt.trimesh_scene(a.grid, 16 / 9)
         d.c.accel = abi.ACCEL_LBVH

@@ -428,6 +428,70 @@ bool world_matches(const PtSceneDesc* d, WorldSig<K...>)
     return true;
 }
 
+// Which part of a world list with reference BVHs and media the library's LBVH can stand for, and
+// the order its leaves are tested in by the in-order walk.  The leading run of shapes and
+// un-wrapped BVHs is taken; a BVH contributes its leaves left to right (the reference's recursion
+// visits them in that order and keeps the right-most of equally near ones, src/ptBVH.cu:45-74);
+// only a BVH at the head of the list is taken, because the walk checks the reference's node boxes
+// against the search bound the tree would be entered with, and that is only known there.
+// A BVH whose leaves mix the two tie kinds (spheres accept t < tmax, everything else t <= tmax)
+// is not taken apart: with mixed kinds a three-way tie between two of its leaves and an earlier
+// entry cannot be settled by comparing candidates two at a time.  Neither is a list that names a
+// shape twice, whose place in the order would be ambiguous.
+struct LbvhPlan {
+    std::vector<PtObject> leaves;
+    std::vector<int32_t> order, group;      // per shape
+    std::vector<float> leaf_gate;           // per shape: box of the reference BVH node naming it (6 floats)
+    int prefix = 0;
+};
+bool lbvh_plan(const PtSceneDesc* d, LbvhPlan* plan)
+{
+    plan->order.assign((size_t)d->n_shapes, -1);
+    plan->group.assign((size_t)d->n_shapes, -1);
+    plan->leaf_gate.assign((size_t)d->n_shapes * 6, 0.0f);
+    auto add = [&](int shape, int group) {
+        if (!plan->leaves.empty() && plan->leaves.back().index == shape && plan->group[shape] == group) return true;   // a one-leaf node names its leaf twice
+        if (plan->order[shape] >= 0) return false;
+        plan->order[shape] = (int32_t)plan->leaves.size();
+        plan->group[shape] = group;
+        PtObject o; o.type = PT_OBJ_SHAPE; o.index = shape;
+        plan->leaves.push_back(o);
+        return true;
+    };
+    int i = 0;
+    for (; i < d->n_world; i++) {
+        const PtObject& ob = d->world[i];
+        if (ob.type == PT_OBJ_SHAPE) { if (!add(ob.index, -1)) return false; continue; }
+        // only a BVH the list starts with: its search bound is then the caller's (see world_hit)
+        if (ob.type != PT_OBJ_BVH || i != 0 || d->bvhs[ob.index].xform_count != 0) break;
+        std::vector<int> stack;                           // links; in-order = left subtree, then right
+        stack.push_back(d->bvhs[ob.index].root);
+        int kind = -1;
+        size_t guard = 0;
+        while (!stack.empty()) {
+            const int link = stack.back(); stack.pop_back();
+            if (++guard > (size_t)4 * (size_t)(d->n_bvh_nodes + 1)) return false;      // not a tree
+            if (link < 0) {
+                const int shape = ~link;
+                const int k = (d->shapes[shape].type == PT_SHAPE_SPHERE || d->shapes[shape].type == PT_SHAPE_MOVING_SPHERE) ? 0 : 1;
+                if (kind >= 0 && k != kind) return false;
+                kind = k;
+                if (!add(shape, ob.index)) return false;
+            } else {
+                const PtBvhNode& nd = d->bvh_nodes[link];
+                for (int child : { nd.left, nd.right }) {
+                    if (child >= 0) continue;
+                    for (int k = 0; k < 3; k++) { plan->leaf_gate[(size_t)~child * 6 + k] = nd.bmin[k]; plan->leaf_gate[(size_t)~child * 6 + 3 + k] = nd.bmax[k]; }
+                }
+                stack.push_back(nd.right);
+                stack.push_back(nd.left);
+            }
+        }
+    }
+    plan->prefix = i;
+    return plan->leaves.size() >= 2;
+}
+
 // The signature walk's constants, one slot per world entry (layout: world_entry in pt_device.h).
 std::vector<float> signature_table(const PtSceneDesc* d)
 {
@@ -634,19 +698,42 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     sc->n_shapes = desc->n_shapes;
     sc->n_media = desc->n_media;
 
-    // Library-built LBVH over the world list (in place of BVH::BVH + quickSort).
-    const bool list_only_shapes = !(mask & (F_MEDIUM | F_REFBVH));
-    if (desc->accel == PT_ACCEL_LBVH && list_only_shapes && desc->n_world >= 2) {
+    // Library-built LBVH over the world list (in place of BVH::BVH + quickSort).  A list of shapes
+    // goes into the tree whole.  A list with reference BVHs and media goes in up to its first
+    // medium (or wrapped BVH): the shapes and the BVHs' leaves of that leading run become the
+    // tree's leaves and the walk continues in list order behind it (lbvh_plan).
+    v.lbvh_order = nullptr; v.lbvh_group = nullptr; v.ref_leaf_gate = nullptr;
+    v.lbvh_prefix = desc->n_world;
+    if (desc->accel == PT_ACCEL_LBVH && desc->n_world >= 2 && !(mask & F_IMAGE)) {
         void* d_nodes = nullptr;
-        int n_nodes = 0, root = 0;
-        const int rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
-        if (rc != PT_OK) { pt_scene_destroy(sc); return rc; }
-        sc->allocs.push_back(d_nodes);
-        v.lbvh = static_cast<const LbvhNode*>(d_nodes);
-        v.lbvh_root = root;
-        v.lbvh_cull = (mask & F_TRIANGLE) ? 0 : 1;
-        sc->lbvh_nodes = n_nodes;
-        mask |= F_LBVH;
+        int n_nodes = 0, root = 0, rc = PT_OK;
+        bool built = false;
+        if (!(mask & (F_MEDIUM | F_REFBVH))) {
+            rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
+            built = true;
+        } else {
+            LbvhPlan plan;
+            if (lbvh_plan(desc, &plan)) {
+                rc = pt::lbvh_build_leaves(plan.leaves.data(), (int)plan.leaves.size(), desc->camera[21], desc->camera[22],
+                                           v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
+                if (rc == PT_OK && !(upload(sc, plan.order.data(), plan.order.size(), &v.lbvh_order, "upload leaf order") &&
+                                     upload(sc, plan.group.data(), plan.group.size(), &v.lbvh_group, "upload leaf groups") &&
+                                     upload(sc, plan.leaf_gate.data(), plan.leaf_gate.size(), &v.ref_leaf_gate, "upload leaf gates"))) {
+                    (void)hipFree(d_nodes); pt_scene_destroy(sc); return PT_ERR_HIP;
+                }
+                v.lbvh_prefix = plan.prefix;
+                built = true;
+            }
+        }
+        if (built) {
+            if (rc != PT_OK) { pt_scene_destroy(sc); return rc; }
+            sc->allocs.push_back(d_nodes);
+            v.lbvh = static_cast<const LbvhNode*>(d_nodes);
+            v.lbvh_root = root;
+            v.lbvh_cull = (mask & F_TRIANGLE) ? 0 : 1;
+            sc->lbvh_nodes = n_nodes;
+            mask |= F_LBVH;
+        }
     }
     sc->mask = mask;
     sc->variant = pick_variant(mask);
@@ -745,8 +832,8 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
         p->schedule != PT_SCHEDULE_WALK) {
         pt::set_error("render: unknown schedule"); return PT_ERR_INVALID;
     }
-    if (p->schedule == PT_SCHEDULE_WALK && !((sc->mask & ptd::F_LBVH) && p->max_depth >= 1)) {
-        pt::set_error("render: PT_SCHEDULE_WALK needs a world in the library's LBVH and a bounce limit of at least 1");
+    if (p->schedule == PT_SCHEDULE_WALK && !((sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1)) {
+        pt::set_error("render: PT_SCHEDULE_WALK needs the whole world in the library's LBVH and a bounce limit of at least 1");
         return PT_ERR_UNSUPPORTED;
     }
     // Refilling keeps waves full but puts their lanes out of phase; that pays when a bounce is
@@ -758,7 +845,8 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     // REFILL 28.2, WALK 18.3 with 48 waiting lanes (32: 21.7, 40: 19.2, 44: 18.5, 52: 18.7).
     if (p->schedule == PT_SCHEDULE_AUTO && sc->variant >= 0 && sc->variant < 6 && k_masks[sc->variant] == M_SPHERES_LBVH) ra.refill = 0;
     if (p->schedule == PT_SCHEDULE_WALK ||
-        (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & ptd::F_TRIANGLE) && p->max_depth >= 1)) ra.refill = 2;
+        (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & ptd::F_TRIANGLE) &&
+         sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1)) ra.refill = 2;
     ra.walk_wait = 48;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);

@@ -71,6 +71,10 @@ struct SceneView {
     const int32_t*    lights;
     const LbvhNode*   lbvh;
     const float*      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
+    const int32_t*    lbvh_order;   // per shape: its place in the sequence of tests the in-order walk makes (nullptr: the shape index)
+    const int32_t*    lbvh_group;   // per shape: the reference BVH it is a leaf of, -1 for a list entry (with lbvh_order)
+    const float*      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
+    int32_t lbvh_prefix;        // world entries the LBVH stands for; the list walk continues from there
     int32_t n_world, n_lights, lights_is_list, ambient_type;
     int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
     int32_t lbvh_cull;          // 1: prune by distance (no triangles in the tree)
@@ -594,7 +598,17 @@ __device__ __forceinline__ bool list_order_better(const SceneView& sv, float t, 
 {
     if (t < best_t) return true;
     if (t > best_t) return false;
-    if (id > best_id) return inclusive_kind(sv.shapes[id].type);
+    int oa = id, ob = best_id;
+    if (sv.lbvh_order) {
+        // Leaves of one reference BVH: the tree keeps the right-most of its nearest leaves whatever
+        // their kind (src/ptBVH.cu:54-57).  Such a tree is only taken into the LBVH when all its
+        // leaves are of one kind, which keeps this rule and the list's rule below consistent when
+        // three candidates tie.
+        const int ga = sv.lbvh_group[id];
+        oa = sv.lbvh_order[id]; ob = sv.lbvh_order[best_id];
+        if (ga >= 0 && ga == sv.lbvh_group[best_id]) return oa > ob;
+    }
+    if (oa > ob) return inclusive_kind(sv.shapes[id].type);
     return !inclusive_kind(sv.shapes[best_id].type);
 }
 
@@ -803,15 +817,37 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
     if constexpr (!is_any_world<W>::value) {
         return world_hit_sig<F, is_branchless<W>::value>(sv, r, tmin, tmax, h, W{});
     }
-    if (F & F_LBVH) {
-        float t; int id, face;
-        if (lbvh_t<F>(sv, r, tmin, tmax, t, id, face, lbvh_stack)) { h.t = t; h.id = id; h.face = face; return true; }
-        return false;
-    }
     bool any = false;
     float closest = tmax;
+    int first = 0;
+    if (F & F_LBVH) {
+        // The tree stands for the first lbvh_prefix entries of the list (all of it when the list
+        // holds shapes only); media and what follows them are walked in list order from there.
+        float t; int id, face;
+        if (lbvh_t<F>(sv, r, tmin, tmax, t, id, face, lbvh_stack)) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
+        if (!(F & (F_MEDIUM | F_REFBVH))) return any;
+        first = sv.lbvh_prefix;
+        if ((F & F_REFBVH) && any && sv.lbvh_group) {
+            // The nearest leaf came out of the reference BVH the list starts with.  The reference only
+            // finds it if the box of every node above it lets the ray in (AABB::hit,
+            // include/ptAABB.h:30-48), and that test can turn away a ray that grazes a box edge although
+            // the leaf's own test accepts it.  Boxes grow towards the root and the test is monotone in
+            // the box (its subtractions, multiplications and comparisons all are), so the box of the
+            // node that names the leaf decides for all of them; the bound is the caller's, because
+            // nothing precedes that tree in the list.  If the box says no -- about once in 10^7 searches
+            // on the RTNW final scene -- the ray is searched again the reference's way, in list order.
+            if (sv.lbvh_group[id] >= 0) {
+                const float* gate = sv.ref_leaf_gate + 6 * (size_t)id;
+                const V3 inv = mk(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+                if (!aabb_hit_inv(gate, gate + 3, r.o, inv, tmin, tmax)) {
+                    any = false; closest = tmax; first = 0;
+                    h.id = PT_ID_MISS; h.face = 0; h.t = tmax;
+                }
+            }
+        }
+    }
     const int n = sv.n_world;
-    for (int i = 0; i < n; i++) {
+    for (int i = first; i < n; i++) {
         const PtObject ob = sv.world[i];
         float t; int id = ob.index, face = 0;
         bool hit = false;

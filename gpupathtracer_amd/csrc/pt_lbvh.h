@@ -14,6 +14,12 @@ namespace pt {
 int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,
                void** d_nodes, int* n_nodes, int* root);
 
+// The same tree over an explicit list of n >= 2 leaves (PT_OBJ_SHAPE entries in any order; the
+// caller supplies the tie order the walk needs).  time0 / time1: the shutter interval moving
+// spheres are bounded over (PtSceneDesc::camera[21], [22]).
+int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, const PtShape* d_shapes, const PtXform* d_xforms,
+                      void** d_nodes, int* n_nodes, int* root);
+
 }  // namespace pt
 
 #endif

@@ -255,7 +255,16 @@ int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* 
             return PT_ERR_UNSUPPORTED;
         }
     }
+    return lbvh_build_leaves(desc->world, n, desc->camera[21], desc->camera[22], d_shapes, d_xforms, d_nodes_out, n_nodes_out, root_out);
+}
+
+int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, const PtShape* d_shapes, const PtXform* d_xforms,
+                      void** d_nodes_out, int* n_nodes_out, int* root_out)
+{
+    *d_nodes_out = nullptr; *n_nodes_out = 0; *root_out = 0;
     if (n < 2) { set_error("lbvh_build: fewer than two shapes"); return PT_ERR_INVALID; }
+    for (int i = 0; i < n; i++)
+        if (leaves[i].type != PT_OBJ_SHAPE) { set_error("lbvh_build: a leaf that is not a shape"); return PT_ERR_UNSUPPORTED; }
 
     const int n_int = n - 1;
     const int n_tiles = (n + TILE - 1) / TILE;
@@ -268,13 +277,13 @@ int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* 
         return PT_ERR_OOM;
     }
     hipError_t e;
-    if ((e = hipMemcpy(world.p, desc->world, (size_t)n * sizeof(PtObject), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "copy world");
+    if ((e = hipMemcpy(world.p, leaves, (size_t)n * sizeof(PtObject), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "copy world");
     const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
     if ((e = hipMemcpy(cb.p, init, sizeof init, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "init bounds");
 
     const int B = 256, G = (n + B - 1) / B, GI = (n_int + B - 1) / B;
     hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, nullptr, d_shapes, d_xforms, world.as<PtObject>(), n,
-                       desc->camera[21], desc->camera[22], boxes.as<Box>(), cb.as<unsigned>());
+                       time0, time1, boxes.as<Box>(), cb.as<unsigned>());
     hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, nullptr, boxes.as<Box>(), n, cb.as<unsigned>(), keys_a.as<uint64_t>());
     // the low 32 key bits (leaf number) are already ascending: four stable passes over the Morton bits
     uint64_t* src = keys_a.as<uint64_t>();

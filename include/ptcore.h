@@ -78,9 +78,15 @@ enum PtAmbientType { PT_AMBIENT_NONE = 0, PT_AMBIENT_CONSTANT = 1, PT_AMBIENT_SK
 /* How the library may search the world list. */
 enum PtAccel {
     PT_ACCEL_LIST = 0,        /* walk the list in order, exactly as HitableList::hit does           */
-    PT_ACCEL_LBVH = 1         /* library-built Morton LBVH over the list; same closest hit and the  */
-                              /* same winner on exact ties as the in-order walk (needs a list made  */
-                              /* only of PT_OBJ_SHAPE entries; otherwise falls back to LIST)        */
+    PT_ACCEL_LBVH = 1         /* library-built Morton LBVH; same closest hit and the same winner on  */
+                              /* exact ties as the in-order walk.  A list of PT_OBJ_SHAPE entries    */
+                              /* goes into the tree whole.  A list that starts with an un-wrapped    */
+                              /* reference BVH (leaves of one tie kind) and/or shapes goes in up to  */
+                              /* its first medium or further BVH -- the BVH's leaves become leaves   */
+                              /* of the tree, with the reference tree's own answer kept where its   */
+                              /* node boxes turn a ray away -- and is walked in order from there.    */
+                              /* Scenes with image textures and lists the tree cannot stand for      */
+                              /* fall back to LIST.                                                  */
 };
 
 /* Which scheduler runs the radiance pipeline stages. */

@@ -572,3 +572,132 @@ def test_shared_walk_needs_the_lbvh():
     with pytest.raises(pt.PtError) as e:
         sc.render(8, 8, 1, schedule=abi.SCHEDULE_WALK)
     assert e.value.code == abi.ERR_UNSUPPORTED
+
+
+def test_lbvh_stands_for_the_leading_run_of_a_mixed_list(oracle):
+    """PT_ACCEL_LBVH on a list with a reference BVH and media (RTNW final): the shapes and the BVH's
+    leaves up to the first medium become the tree's leaves, the media and what follows are walked
+    in list order behind it.  Same hits and same image as the reference's own tree walk."""
+    d_list = pt.builtin_scene("final", 16 / 9)
+    d = pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH)
+    sc = pt.Scene(d)
+    assert len(sc.lbvh_nodes()) == 400 + 5 - 1                # 400 boxes and the five shapes in front of the first medium
+    rays = np.concatenate([oracle.record_rays(d_list, 64, 36, 6, 80000), random_rays(np.random.default_rng(21), 40000, -200, 800)])
+    ids_o, t_o = oracle.trace_closest(d_list, rays)
+    ids_g, t_g = sc.trace_closest(rays)
+    assert (ids_o >= abi.ID_MEDIUM_BASE).sum() > 100          # the fog answers too
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+    for nx, ny, ns, depth in ((96, 54, 6, 25), (33, 19, 3, 2)):
+        ref = oracle.render(d_list, nx, ny, ns, depth)
+        for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
+            assert_bit_exact(sc.render(nx, ny, ns, depth, schedule=schedule), ref, "final through the LBVH, schedule %d" % schedule)
+    assert_bit_exact(sc.render(48, 27, 3, pipeline=abi.PIPELINE_WAVEFRONT), oracle.render(d_list, 48, 27, 3), "final through the LBVH, staged")
+    with pytest.raises(pt.PtError):                           # the shared walk needs the whole world in the tree
+        sc.render(8, 8, 1, schedule=abi.SCHEDULE_WALK)
+
+    # Rays aimed at the edges of the boxes' top faces: the reference's node boxes turn some of them
+    # away although the box's own test would accept them (AABB::hit rounds differently from the
+    # rectangle test), so the reference tree's answer is not always the nearest of all leaves.  The
+    # library's tree must give the reference tree's answer, not the brute-force one.
+    from tests._desc_tools import OwnedDesc
+    rng = np.random.default_rng(8)
+    c = d_list.c
+    n = 300_000
+    box = rng.integers(0, 400, n)
+    q = np.array([[c.shapes[int(b)].p[k] for k in range(6)] for b in range(400)], np.float32)[box]
+    target = np.stack([np.where(rng.random(n) < 0.5, q[:, 0], q[:, 3]), q[:, 4], rng.uniform(q[:, 2], q[:, 5])], axis=1).astype(np.float32)
+    edge = random_rays(rng, n, 0, 1)
+    edge["o"] = target + np.stack([rng.uniform(-300, 300, n), rng.uniform(50, 600, n), rng.uniform(-300, 300, n)], axis=1).astype(np.float32)
+    edge["d"] = target - edge["o"]
+    ids_o, t_o = oracle.trace_closest(d_list, edge)
+    ids_g, t_g = sc.trace_closest(edge)
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+    flat = OwnedDesc(d_list)                                   # the same shapes as one flat list: brute force
+    w = flat.lists["world"]
+    leaves = []
+    for i in range(400):
+        o = abi.PtObject(); o.type = abi.OBJ_SHAPE; o.index = i
+        leaves.append(o)
+    flat.lists["world"] = leaves + list(w[1:])
+    flat.lists["bvhs"], flat.lists["bvh_nodes"] = [], []
+    flat.finalize()
+    ids_f, t_f = oracle.trace_closest(flat, edge)
+    assert ((ids_f != ids_o) | (bits(t_f) != bits(t_o))).sum() > 0, "no ray of this set separates the reference tree from brute force"
+
+
+def test_lbvh_keeps_the_reference_trees_tie_rule(oracle):
+    """Leaves of one reference BVH that tie exactly: the tree keeps the right-most in its own
+    order (not the order of the shape table), and a list entry at the same distance keeps the hit
+    against the tree's spheres when it comes first and loses it when it comes second; a rectangle
+    in the plane of a box top that follows the tree takes the hit over."""
+    from tests._desc_tools import OwnedDesc
+    rng = np.random.default_rng(4)
+    # boxes: make groups of leaves of the final scene's tree coincide
+    g = OwnedDesc(pt.builtin_scene("final", 16 / 9))
+    shapes = g.lists["shapes"]
+    boxes = [i for i, s in enumerate(shapes) if s.type == abi.SHAPE_BOX]
+    for _ in range(60):
+        a, b = rng.choice(boxes, 2, replace=False)
+        for k in range(6):
+            shapes[b].p[k] = shapes[a].p[k]
+    nodes = g.lists["bvh_nodes"]
+
+    def refit(link):                                              # the tree's boxes must still bound the moved leaves
+        if link < 0:
+            q = shapes[~link].p
+            return [q[0], q[1], q[2]], [q[3], q[4], q[5]]
+        lo_l, hi_l = refit(nodes[link].left)
+        lo_r, hi_r = refit(nodes[link].right)
+        for k in range(3):
+            nodes[link].bmin[k], nodes[link].bmax[k] = min(lo_l[k], lo_r[k]), max(hi_l[k], hi_r[k])
+        return list(nodes[link].bmin), list(nodes[link].bmax)
+    refit(g.lists["bvhs"][0].root)
+    # the list entry after the tree, a rectangle, spread out in the plane of one box's top face
+    ls = shapes[g.lists["world"][1].index]
+    assert ls.type == abi.SHAPE_RECT_XZ
+    ls.p[0], ls.p[1], ls.p[2], ls.p[3] = -2000.0, 2000.0, -2000.0, 2000.0
+    ls.p[4] = shapes[boxes[0]].p[4]
+    rays = random_rays(rng, 150000, -900, 900)
+    rays["o"][:, 1] = np.abs(rays["o"][:, 1]) + 300.0            # from above, looking down
+    rays["d"][:, 1] = -np.abs(rays["d"][:, 1])
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        assert (len(sc.lbvh_nodes()) > 0) == (accel == abi.ACCEL_LBVH)
+        ids_o, t_o = oracle.trace_closest(g, rays)
+        ids_g, t_g = sc.trace_closest(rays)
+        np.testing.assert_array_equal(ids_g, ids_o)
+        np.testing.assert_array_equal(bits(t_g), bits(t_o))
+    assert np.isin(ids_o, boxes).sum() > 1000
+
+    # spheres: a list entry and the two leaves of a hand-made BVH, all the same sphere
+    h = OwnedDesc(pt.builtin_scene("simple_spheres", 2.0))
+    hs = h.lists["shapes"]
+    for j in (2, 3):
+        for k in range(4):
+            hs[j].p[k] = hs[1].p[k]
+    node = abi.PtBvhNode()
+    c, r = [hs[1].p[k] for k in range(3)], hs[1].p[3]
+    for k in range(3):
+        node.bmin[k], node.bmax[k] = c[k] - r, c[k] + r
+    node.left, node.right = ~3, ~2                               # tree order: shape 3, then shape 2
+    bvh = abi.PtBvh(); bvh.root = 0; bvh.xform_first = 0; bvh.xform_count = 0
+    h.lists["bvh_nodes"], h.lists["bvhs"] = [node], [bvh]
+    w = h.lists["world"]
+    tree = abi.PtObject(); tree.type = abi.OBJ_BVH; tree.index = 0
+    srays = random_rays(rng, 40000, -4, 4)
+    for order in ("entry first", "tree first"):
+        h.lists["world"] = [w[0], w[1], tree] if order == "entry first" else [w[0], tree, w[1]]
+        for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+            h.scalars["accel"] = accel
+            h.finalize()
+            sc = pt.Scene(h)
+            ids_o, t_o = oracle.trace_closest(h, srays)
+            ids_g, t_g = sc.trace_closest(srays)
+            np.testing.assert_array_equal(ids_g, ids_o)
+            np.testing.assert_array_equal(bits(t_g), bits(t_o))
+        winners = set(np.unique(ids_o[np.isin(ids_o, [1, 2, 3])]).tolist())
+        assert winners == ({1} if order == "entry first" else {2}), (order, winners)
