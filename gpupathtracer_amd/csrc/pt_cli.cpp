@@ -100,7 +100,7 @@ int main(int argc, char** argv)
     }
     if (accel == "lbvh") desc->accel = PT_ACCEL_LBVH;
     else if (accel == "list") desc->accel = PT_ACCEL_LIST;
-    else if (desc->n_world > 32 && desc->n_media == 0 && desc->n_bvhs == 0) desc->accel = PT_ACCEL_LBVH;
+    else if (desc->n_world > 32 || desc->n_bvhs > 0) desc->accel = PT_ACCEL_LBVH;      // the library falls back to the list where its tree cannot stand for it
 
     const int have = pt_device_count();
     if (have < 1) { std::cerr << "no HIP device is visible" << std::endl; return EXIT_FAILURE; }
