@@ -434,6 +434,42 @@ __device__ __forceinline__ bool shape_t(const SceneView& sv, int index, const Ra
     return false;
 }
 
+// shape_t for a leaf of the library's tree, where the index differs from lane to lane: the whole
+// 64-byte record is fetched at once and the test dispatches on the copy.  shape_t reads the type,
+// waits, and reads the parameters of that type: two memory round trips per leaf.
+template <uint32_t F>
+__device__ __forceinline__ bool leaf_t(const SceneView& sv, int index, const Ray& ray, float tmin, float tmax,
+                                       float& t, int& face)
+{
+    const uint4* w = reinterpret_cast<const uint4*>(&sv.shapes[index]);      // records are 64 bytes, 64-byte aligned
+    const uint4 a = w[0], b = w[1], c = w[2], d = w[3];
+    asm volatile("" :: "v"(a.x), "v"(b.x), "v"(c.x), "v"(d.x));              // all four loads land here
+    const int type = (int)a.x;
+    const float p[10] = { __uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z),
+                          __uint_as_float(c.w), __uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w) };
+    Ray r = ray;
+    if (F & F_XFORM) {
+        const int nx = (int)b.x;
+        if (nx > 0) r = to_local(sv, (int)a.w, nx, ray);
+    }
+    face = 0;
+    if ((F & F_SPHERE) && type == PT_SHAPE_SPHERE)
+        return sphere_t(mk(p[0], p[1], p[2]), p[3], r, tmin, tmax, t);
+    if ((F & F_MSPHERE) && type == PT_SHAPE_MOVING_SPHERE)
+        return sphere_t(msphere_center(p, r.time), p[8], r, tmin, tmax, t);
+    if (F & F_RECT) {
+        if (type == PT_SHAPE_RECT_XY)
+            return rect_t(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, p[0], p[1], p[2], p[3], p[4], tmin, tmax, t);
+        if (type == PT_SHAPE_RECT_XZ)
+            return rect_t(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, p[0], p[1], p[2], p[3], p[4], tmin, tmax, t);
+        if (type == PT_SHAPE_RECT_YZ)
+            return rect_t(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, p[0], p[1], p[2], p[3], p[4], tmin, tmax, t);
+    }
+    if ((F & F_BOX) && type == PT_SHAPE_BOX) return box_t(p, r, tmin, tmax, t, face);
+    if ((F & F_TRIANGLE) && type == PT_SHAPE_TRIANGLE) return triangle_t(p, r, tmin, tmax, t);
+    return false;
+}
+
 // ---- closest hit over the world ---------------------------------------------------------------------
 struct Hit {
     float t;
@@ -671,7 +707,7 @@ __device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, flo
     } else {
         const int id = ~w.cur;
         float t; int face;
-        if (shape_t<F>(sv, id, r, tmin, tmax, t, face)) {
+        if (leaf_t<F>(sv, id, r, tmin, tmax, t, face)) {
             if (!w.any || list_order_better(sv, t, id, w.best, w.best_id)) { w.any = true; w.best = t; w.best_id = id; w.best_face = face; }
         }
     }
