@@ -32,7 +32,9 @@ with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
 # HBM bytes one launch moves, from the committed rocprofv3 PMC pass (FETCH_SIZE + WRITE_SIZE with
 # the guide's unit and gfx950 corrections): the frame is written once, the scene stays in cache.
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "pmc_cornell1024x512_k_render_tiles.json")
-# fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).
+# fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).  Measured
+# (tools/valu_probe.hip): plain add/mul/fma on vector registers issue at that rate; compares, selects,
+# min/max, integer multiplies, fp64, conversions and the scale / fix-up steps of a divide at half of it.
 PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
@@ -175,8 +177,9 @@ def main():
                         "frac": achieved / PEAK_VALU_TFLOPS, "traffic": traffic,
                         "kernel": "k_render_refill" if scene.stats().schedule == 2 else "k_render_tiles",
                         "kernel_ms": k_ms, "flop_per_path": flop, "paths_per_launch": shard_paths,
-                        "peak_note": "fp32 VALU with packed issue, no FMA credit (parity forbids contraction); "
-                                     "%.1f TFLOP/s un-packed" % (PEAK_VALU_TFLOPS / 2)}
+                        "peak_note": "fp32 VALU, one add/mul per lane per cycle, no FMA credit (parity forbids contraction); compares, "
+                                     "selects, min/max, fp64 and divide scale/fix-up steps issue at half that rate (%.1f TFLOP/s)"
+                                     % (PEAK_VALU_TFLOPS / 2)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from tests import _oracle
