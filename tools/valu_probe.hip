@@ -3,6 +3,7 @@
 // in the design notes.   hipcc -O2 --offload-arch=gfx950 -o valu_probe valu_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -12,6 +13,7 @@
 #define PROBE_KERNEL(NAME, ASM8)                                                                     \
     __global__ __launch_bounds__(512) void NAME(float* out, float seed, unsigned long long* cyc)    \
     {                                                                                                \
+        if (seed < 0.0f && (threadIdx.x & 32)) return;      /* half_wave: upper 32 lanes leave */       \
         float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
         float b = seed * 0.5f + 1.0f, c = seed + 0.25f;                                              \
         double d0 = a0, d1 = a1, d2 = a2, d3 = a3, e = b;                                            \
@@ -119,6 +121,8 @@ int main()
     hipMalloc(&cyc, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%d CUs, clock %d kHz; wall-clock cycles per wave-instruction per SIMD at the rated clock, by resident waves per SIMD\n", cus, prop.clockRate);
+    const float seed = (getenv("HALF_WAVE") ? -1.0f : 1.0f);
+    if (seed < 0) printf("upper 32 lanes of every wave inactive\n");
     printf("%-24s %8s %8s %8s %8s\n", "instruction", "1", "2", "4", "8");
     const int insts = 64 * ITERS;
     for (auto& p : probes) {
@@ -126,10 +130,10 @@ int main()
         for (int w : {1, 2, 4, 8}) {
             // one workgroup of 4*w waves per CU puts w waves on every SIMD
             const int block = 64 * 4 * (w > 2 ? 2 : w), grid = cus * (w > 2 ? w / 2 : 1);
-            hipLaunchKernelGGL(p.k, dim3(grid), dim3(block), 0, 0, out, 1.0f, cyc);
+            hipLaunchKernelGGL(p.k, dim3(grid), dim3(block), 0, 0, out, seed, cyc);
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            hipLaunchKernelGGL(p.k, dim3(grid), dim3(block), 0, 0, out, 1.0f, cyc);
+            hipLaunchKernelGGL(p.k, dim3(grid), dim3(block), 0, 0, out, seed, cyc);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double cycles = ms * 1e-3 * prop.clockRate * 1e3;
