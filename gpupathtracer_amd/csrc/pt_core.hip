@@ -704,7 +704,8 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     // tree's leaves and the walk continues in list order behind it (lbvh_plan).
     v.lbvh_order = nullptr; v.lbvh_group = nullptr; v.ref_leaf_gate = nullptr;
     v.lbvh_prefix = desc->n_world;
-    if (desc->accel == PT_ACCEL_LBVH && desc->n_world >= 2 && !(mask & F_IMAGE)) {
+    v.reads_uv = (mask & F_IMAGE) ? 1 : 0;
+    if (desc->accel == PT_ACCEL_LBVH && desc->n_world >= 2) {
         void* d_nodes = nullptr;
         int n_nodes = 0, root = 0, rc = PT_OK;
         bool built = false;

@@ -75,6 +75,7 @@ struct SceneView {
     const int32_t*    lbvh_group;   // per shape: the reference BVH it is a leaf of, -1 for a list entry (with lbvh_order)
     const float*      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
     int32_t lbvh_prefix;        // world entries the LBVH stands for; the list walk continues from there
+    int32_t reads_uv;           // the scene has an image texture (the only reader of a hit's uv)
     int32_t n_world, n_lights, lights_is_list, ambient_type;
     int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
     int32_t lbvh_cull;          // 1: prune by distance (no triangles in the tree)
@@ -856,13 +857,25 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
     bool any = false;
     float closest = tmax;
     int first = 0;
+    bool uv_unknown = false;
+    const Pcg g_before = g;                                    // media draw inside the list walk
     if (F & F_LBVH) {
         // The tree stands for the first lbvh_prefix entries of the list (all of it when the list
         // holds shapes only); media and what follows them are walked in list order from there.
         float t; int id, face;
         if (lbvh_t<F>(sv, r, tmin, tmax, t, id, face, lbvh_stack)) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
-        if (!(F & (F_MEDIUM | F_REFBVH))) return any;
+        if (!(F & (F_MEDIUM | F_REFBVH | F_IMAGE))) return any;
         first = sv.lbvh_prefix;
+        if ((F & F_IMAGE) && sv.reads_uv && any) {
+            // Stale uv (see Hit): a plain sphere reports the uv of the last hit the in-order walk
+            // accepted from a shape that writes uv.  Hits are accepted in decreasing t, so when the
+            // nearest shape of the tree's part of the list writes uv, it is that hit.  When it is a
+            // plain sphere the last uv-writing hit before it is not known here; that only matters if
+            // no later entry writes uv and the search ends on a plain sphere whose texture can read
+            // uv, and then the ray is searched again the in-order way (below).
+            if (writes_uv(sv.shapes[id].type)) { h.uv_id = id; h.uv_face = face; h.uv_t = t; }
+            else uv_unknown = true;
+        }
         if ((F & F_REFBVH) && any && sv.lbvh_group) {
             // The nearest leaf came out of the reference BVH the list starts with.  The reference only
             // finds it if the box of every node above it lets the ray in (AABB::hit,
@@ -883,24 +896,39 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
         }
     }
     const int n = sv.n_world;
-    for (int i = first; i < n; i++) {
-        const PtObject ob = sv.world[i];
-        float t; int id = ob.index, face = 0;
-        bool hit = false;
-        if (!(F & (F_MEDIUM | F_REFBVH)) || ob.type == PT_OBJ_SHAPE) {
-            hit = shape_t<F>(sv, ob.index, r, tmin, closest, t, face);
-        } else if ((F & F_MEDIUM) && ob.type == PT_OBJ_MEDIUM) {
-            hit = medium_t<F>(sv, ob.index, r, tmin, closest, t, g);
-            id = PT_ID_MEDIUM_BASE + ob.index;
-        } else if ((F & F_REFBVH) && ob.type == PT_OBJ_BVH) {
-            hit = refbvh_t<F>(sv, ob.index, r, tmin, closest, t, id, face, lbvh_stack);
-        }
-        if (hit) {
-            any = true; closest = t; h.t = t; h.id = id; h.face = face;
-            if (F & F_IMAGE) {
-                if (id < PT_ID_MEDIUM_BASE && writes_uv(sv.shapes[id].type)) { h.uv_id = id; h.uv_face = face; h.uv_t = t; }
+    while (true) {
+        for (int i = first; i < n; i++) {
+            const PtObject ob = sv.world[i];
+            float t; int id = ob.index, face = 0;
+            bool hit = false;
+            if (!(F & (F_MEDIUM | F_REFBVH)) || ob.type == PT_OBJ_SHAPE) {
+                hit = shape_t<F>(sv, ob.index, r, tmin, closest, t, face);
+            } else if ((F & F_MEDIUM) && ob.type == PT_OBJ_MEDIUM) {
+                hit = medium_t<F>(sv, ob.index, r, tmin, closest, t, g);
+                id = PT_ID_MEDIUM_BASE + ob.index;
+            } else if ((F & F_REFBVH) && ob.type == PT_OBJ_BVH) {
+                hit = refbvh_t<F>(sv, ob.index, r, tmin, closest, t, id, face, lbvh_stack);
+            }
+            if (hit) {
+                any = true; closest = t; h.t = t; h.id = id; h.face = face;
+                if (F & F_IMAGE) {
+                    if (id < PT_ID_MEDIUM_BASE && writes_uv(sv.shapes[id].type)) { h.uv_id = id; h.uv_face = face; h.uv_t = t; uv_unknown = false; }
+                }
             }
         }
+        if (!((F & F_LBVH) && (F & F_IMAGE))) break;
+        // the one case the tree could not settle: the search ends on a plain sphere that may read a uv the tree did not see
+        bool again = false;
+        if (uv_unknown && any && h.id < PT_ID_MEDIUM_BASE && !writes_uv(sv.shapes[h.id].type)) {
+            const int m = sv.shapes[h.id].material;
+            const int tex = m >= 0 ? sv.materials[m].texture : -1;
+            const int kind = tex >= 0 ? sv.textures[tex].type : PT_TEX_CONSTANT;
+            again = kind == PT_TEX_IMAGE || kind == PT_TEX_CHECKER;
+        }
+        if (!again) break;
+        uv_unknown = false; g = g_before; first = 0;
+        any = false; closest = tmax;
+        h.id = PT_ID_MISS; h.face = 0; h.t = tmax; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
     }
     return any;
 }

@@ -85,8 +85,7 @@ enum PtAccel {
                               /* its first medium or further BVH -- the BVH's leaves become leaves   */
                               /* of the tree, with the reference tree's own answer kept where its   */
                               /* node boxes turn a ray away -- and is walked in order from there.    */
-                              /* Scenes with image textures and lists the tree cannot stand for      */
-                              /* fall back to LIST.                                                  */
+                              /* Lists the tree cannot stand for fall back to LIST.                  */
 };
 
 /* Which scheduler runs the radiance pipeline stages. */

@@ -123,8 +123,14 @@ def test_final_scene_with_image_texture(oracle):
     tex = np.random.default_rng(2).integers(0, 256, (32, 64, 3), dtype=np.uint8)
     d = pt.builtin_scene("final", 16 / 9, earth_rgb=tex)
     assert d.c.n_world == 10
-    img = pt.Scene(d).render(96, 54, 8)
-    assert_bit_exact(img, oracle.render(d, 96, 54, 8), "final + image texture")
+    ref = oracle.render(d, 96, 54, 8)
+    assert_bit_exact(pt.Scene(d).render(96, 54, 8), ref, "final + image texture")
+    # through the library's tree: the uv a plain sphere reports depends on which hits the in-order
+    # walk accepted before it, which the tree knows only when its nearest shape writes uv itself
+    d2 = pt.builtin_scene("final", 16 / 9, earth_rgb=tex, accel=abi.ACCEL_LBVH)
+    sc = pt.Scene(d2)
+    assert len(sc.lbvh_nodes()) > 0
+    assert_bit_exact(sc.render(96, 54, 8), ref, "final + image texture through the LBVH")
 
 
 @pytest.mark.parametrize("nx,ny,ns,depth", [(37, 21, 3, 25), (1, 1, 5, 25), (8, 8, 1, 25), (33, 9, 4, 0), (33, 9, 4, 1), (16, 16, 2, 3)])
