@@ -437,7 +437,7 @@ bool world_matches(const PtSceneDesc* d, WorldSig<K...>)
 // A BVH whose leaves mix the two tie kinds (spheres accept t < tmax, everything else t <= tmax)
 // is not taken apart: with mixed kinds a three-way tie between two of its leaves and an earlier
 // entry cannot be settled by comparing candidates two at a time.  Neither is a list that names a
-// shape twice, whose place in the order would be ambiguous.
+// shape twice, whose place in the order would be ambiguous, nor a tree whose boxes do not nest.
 struct LbvhPlan {
     std::vector<PtObject> leaves;
     std::vector<int32_t> order, group;      // per shape
@@ -480,7 +480,13 @@ bool lbvh_plan(const PtSceneDesc* d, LbvhPlan* plan)
             } else {
                 const PtBvhNode& nd = d->bvh_nodes[link];
                 for (int child : { nd.left, nd.right }) {
-                    if (child >= 0) continue;
+                    if (child >= 0) {
+                        // the walk lets one box speak for all the boxes above it (world_hit): they must nest
+                        const PtBvhNode& ch = d->bvh_nodes[child];
+                        for (int k = 0; k < 3; k++)
+                            if (!(nd.bmin[k] <= ch.bmin[k] && ch.bmax[k] <= nd.bmax[k])) return false;
+                        continue;
+                    }
                     for (int k = 0; k < 3; k++) { plan->leaf_gate[(size_t)~child * 6 + k] = nd.bmin[k]; plan->leaf_gate[(size_t)~child * 6 + 3 + k] = nd.bmax[k]; }
                 }
                 stack.push_back(nd.right);
@@ -709,7 +715,10 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         void* d_nodes = nullptr;
         int n_nodes = 0, root = 0, rc = PT_OK;
         bool built = false;
-        if (!(mask & (F_MEDIUM | F_REFBVH))) {
+        bool in_table_order = !(mask & (F_MEDIUM | F_REFBVH));     // shapes only, listed in the order of the shape table:
+        for (int i = 1; i < desc->n_world && in_table_order; i++)     // then the shape index is the tie order
+            in_table_order = desc->world[i].index > desc->world[i - 1].index;
+        if (in_table_order) {
             rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
             built = true;
         } else {

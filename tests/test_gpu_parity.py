@@ -707,3 +707,131 @@ def test_lbvh_keeps_the_reference_trees_tie_rule(oracle):
             np.testing.assert_array_equal(bits(t_g), bits(t_o))
         winners = set(np.unique(ids_o[np.isin(ids_o, [1, 2, 3])]).tolist())
         assert winners == ({1} if order == "entry first" else {2}), (order, winners)
+
+
+def _random_world(rng, base):
+    """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
+    rectangles (some flipped, some wrapped boxes), an optional reference BVH at the head of the
+    list or later in it (median splits, boxes = unions of the leaves' bounds), optional media."""
+    from tests._desc_tools import OwnedDesc
+    from gpupathtracer_amd import _abi as A
+    g = OwnedDesc(base)
+    mats = [i for i, m in enumerate(g.lists["materials"])]
+    shapes, xforms, bounds = [], [], []
+
+    def add(kind, p, flags=0, xf=None):
+        s = A.PtShape(type=kind, flags=flags, material=int(rng.choice(mats)), xform_first=0, xform_count=0, tri_uv=-1)
+        for k, v in enumerate(p):
+            s.p[k] = float(np.float32(v))
+        if xf is not None:
+            s.xform_first = len(xforms)
+            s.xform_count = 2
+            ang = np.float32(xf[3])
+            xforms.append(A.PtXform(type=abi.XFORM_TRANSLATE, v=(C.c_float * 3)(float(xf[0]), float(xf[1]), float(xf[2]))))
+            xforms.append(A.PtXform(type=abi.XFORM_ROTATE_Y, v=(C.c_float * 3)(float(np.sin(ang, dtype=np.float32)), float(np.cos(ang, dtype=np.float32)), 0.0)))
+        shapes.append(s)
+        return len(shapes) - 1
+
+    import ctypes as C
+    n = int(rng.integers(12, 90))
+    plain = []                                                 # (shape id, kind class, lo, hi): candidates for a reference BVH
+    for _ in range(n):
+        c = rng.uniform(-50, 50, 3).astype(np.float32)
+        r = np.float32(rng.uniform(1, 12))
+        k = rng.integers(0, 6)
+        if k == 0:
+            i = add(abi.SHAPE_SPHERE, [c[0], c[1], c[2], r])
+            plain.append((i, 0, c - r, c + r))
+        elif k == 1:
+            c1 = (c + rng.uniform(-5, 5, 3)).astype(np.float32)
+            i = add(abi.SHAPE_MOVING_SPHERE, [c[0], c[1], c[2], c1[0], c1[1], c1[2], 0.0, 1.0, r])
+            plain.append((i, 0, np.minimum(c, c1) - r, np.maximum(c, c1) + r))
+        elif k == 2:
+            e = rng.uniform(2, 15, 3).astype(np.float32)
+            i = add(abi.SHAPE_BOX, [c[0], c[1], c[2], c[0] + e[0], c[1] + e[1], c[2] + e[2]])
+            plain.append((i, 1, c.copy(), c + e))
+        elif k == 3:
+            e = rng.uniform(2, 15, 3).astype(np.float32)
+            add(abi.SHAPE_BOX, [0, 0, 0, e[0], e[1], e[2]], xf=(c[0], c[1], c[2], rng.uniform(-1, 1)))
+        else:
+            kind = (abi.SHAPE_RECT_XY, abi.SHAPE_RECT_XZ, abi.SHAPE_RECT_YZ)[int(rng.integers(0, 3))]
+            e = rng.uniform(3, 25, 2).astype(np.float32)
+            i = add(kind, [c[0], c[0] + e[0], c[1], c[1] + e[1], c[2]], flags=abi.FLIP_NORMAL if rng.random() < 0.3 else 0)
+            ax = {abi.SHAPE_RECT_XY: (0, 1, 2), abi.SHAPE_RECT_XZ: (0, 2, 1), abi.SHAPE_RECT_YZ: (1, 2, 0)}[kind]
+            lo = np.zeros(3, np.float32); hi = np.zeros(3, np.float32)
+            lo[ax[0]], hi[ax[0]] = c[0], c[0] + e[0]
+            lo[ax[1]], hi[ax[1]] = c[1], c[1] + e[1]
+            lo[ax[2]], hi[ax[2]] = c[2] - np.float32(1e-4), c[2] + np.float32(1e-4)
+            plain.append((i, 1, lo, hi))
+    nodes = []
+
+    def build(items):                                          # returns (link, lo, hi)
+        if len(items) == 1:
+            return ~items[0][0], items[0][2], items[0][3]
+        ax = int(rng.integers(0, 3))
+        items = sorted(items, key=lambda it: float(it[2][ax]))
+        mid = len(items) // 2
+        l, llo, lhi = build(items[:mid])
+        r, rlo, rhi = build(items[mid:])
+        lo, hi = np.minimum(llo, rlo), np.maximum(lhi, rhi)
+        nd = A.PtBvhNode(left=l, right=r)
+        for k in range(3):
+            nd.bmin[k], nd.bmax[k] = float(lo[k]), float(hi[k])
+        nodes.append(nd)                                       # children before parents, as the library requires
+        return len(nodes) - 1, lo, hi
+
+    world, bvhs, in_tree = [], [], set()
+    tree_kind = int(rng.integers(0, 4))                        # 0 none, 1 one kind of leaf, 2 mixed kinds, 3 one kind, not at the head
+    if tree_kind and len(plain) >= 6:
+        one_kind = int(rng.integers(0, 2))
+        pool = plain if tree_kind == 2 else [it for it in plain if it[1] == one_kind]
+        pool = [pool[i] for i in rng.permutation(len(pool))[:max(2, len(pool) // 2)]] if len(pool) >= 2 else []
+        if len(pool) >= 2:
+            root, _, _ = build(pool)
+            bvhs.append(A.PtBvh(root=root, xform_first=0, xform_count=0))
+            in_tree = {it[0] for it in pool}
+    rest = [i for i in range(len(shapes)) if i not in in_tree]
+    rest = [rest[i] for i in rng.permutation(len(rest))]
+    boundary = None
+    media = []
+    spheres = [i for i in rest if shapes[i].type == abi.SHAPE_SPHERE]
+    if spheres and rng.random() < 0.6:
+        boundary = spheres[0]
+        iso = next(i for i, m in enumerate(g.lists["materials"]) if m.type == abi.MAT_ISOTROPIC)
+        media.append(A.PtMedium(boundary=boundary, density=0.02, material=iso))
+    entries = [A.PtObject(type=abi.OBJ_SHAPE, index=i) for i in rest]
+    if media:
+        entries.insert(int(rng.integers(len(entries) // 2, len(entries) + 1)), A.PtObject(type=abi.OBJ_MEDIUM, index=0))
+    if bvhs:
+        pos = 0 if tree_kind != 3 else int(rng.integers(1, len(entries) + 1))
+        entries.insert(pos, A.PtObject(type=abi.OBJ_BVH, index=0))
+    g.lists["shapes"], g.lists["xforms"], g.lists["bvh_nodes"], g.lists["bvhs"] = shapes, xforms, nodes, bvhs
+    g.lists["media"], g.lists["world"] = media, entries
+    g.lists["lights"] = []
+    g.scalars["lights_is_list"] = 0
+    return g
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_worlds_match_the_oracle(oracle, seed):
+    """Closest hits and a small image for random worlds, walked in list order and through the
+    library's tree: lists in arbitrary order, reference BVHs with one or mixed kinds of leaves, at
+    the head of the list or not (the tree only takes what it can stand for), media, wrapped boxes."""
+    rng = np.random.default_rng(1000 + seed)
+    g = _random_world(rng, pt.builtin_scene("final", 16 / 9))
+    cam = pt.builtin_scene("simple_spheres", 2.0).c.camera
+    g.camera = [float(cam[k]) * (12.0 if k < 3 else 1.0) for k in range(24)]
+    rays = random_rays(rng, 30000, -70, 70)
+    ref = None
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        ids_o, t_o = oracle.trace_closest(g, rays)
+        ids_g, t_g = sc.trace_closest(rays)
+        assert (ids_o != abi.ID_MISS).mean() > 0.05
+        np.testing.assert_array_equal(ids_g, ids_o)
+        np.testing.assert_array_equal(bits(t_g), bits(t_o))
+        if ref is None:
+            ref = oracle.render(g, 40, 20, 3)
+        assert_bit_exact(sc.render(40, 20, 3), ref, "random world %d accel %d" % (seed, accel))
