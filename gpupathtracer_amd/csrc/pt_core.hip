@@ -10,6 +10,7 @@
 //   * k_trace_closest: world->hit for a batch of rays (closest-hit parity entry point).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -249,9 +250,12 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
         if (mode == WALKED) {                                 // the rest of the bounce, as in lane_step
             Hit h;
             h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
+            bool any = w.any;
+            if (any) { h.t = w.best; h.id = w.best_id; h.face = w.best_face; }
+            if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray)))       // see accepts_nan: the list, in order
+                any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
             bool ended;
-            if (w.any) {
-                h.t = w.best; h.id = w.best_id; h.face = w.best_face;
+            if (any) {
                 ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
             } else {
                 shade_miss<F>(sv, st.ray, st.thr);
@@ -709,12 +713,19 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     // medium (or wrapped BVH): the shapes and the BVHs' leaves of that leading run become the
     // tree's leaves and the walk continues in list order behind it (lbvh_plan).
     v.lbvh_order = nullptr; v.lbvh_group = nullptr; v.ref_leaf_gate = nullptr;
+    v.tree_planes = nullptr; v.tree_plane_end[0] = v.tree_plane_end[1] = v.tree_plane_end[2] = 0; v.tree_wrapped = 0;
     v.lbvh_prefix = desc->n_world;
     v.reads_uv = (mask & F_IMAGE) ? 1 : 0;
-    if (desc->accel == PT_ACCEL_LBVH && desc->n_world >= 2) {
+    bool tree_sized = true;                                    // see ray_may_enter_tree: shapes within 2^40
+    for (int i = 0; i < desc->n_shapes && tree_sized; i++)
+        for (float q : desc->shapes[i].p) if (!(std::fabs(q) <= ptd::TREE_RAY_LIMIT)) tree_sized = false;
+    for (int i = 0; i < desc->n_xforms && tree_sized; i++)
+        for (float q : desc->xforms[i].v) if (!(std::fabs(q) <= ptd::TREE_RAY_LIMIT)) tree_sized = false;
+    if (desc->accel == PT_ACCEL_LBVH && desc->n_world >= 2 && tree_sized) {
         void* d_nodes = nullptr;
         int n_nodes = 0, root = 0, rc = PT_OK;
         bool built = false;
+        LbvhPlan plan;
         bool in_table_order = !(mask & (F_MEDIUM | F_REFBVH));     // shapes only, listed in the order of the shape table:
         for (int i = 1; i < desc->n_world && in_table_order; i++)     // then the shape index is the tie order
             in_table_order = desc->world[i].index > desc->world[i - 1].index;
@@ -722,7 +733,6 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
             rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
             built = true;
         } else {
-            LbvhPlan plan;
             if (lbvh_plan(desc, &plan)) {
                 rc = pt::lbvh_build_leaves(plan.leaves.data(), (int)plan.leaves.size(), desc->camera[21], desc->camera[22],
                                            v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
@@ -734,6 +744,33 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
                 v.lbvh_prefix = plan.prefix;
                 built = true;
             }
+        }
+        if (built && rc == PT_OK) {
+            // plane coordinates of the tree's un-wrapped rectangles and box faces, per axis (ray_may_enter_tree)
+            std::vector<float> planes[3];
+            bool wrapped = false;
+            const PtObject* leaves = in_table_order ? desc->world : plan.leaves.data();
+            const size_t n_leaves = in_table_order ? (size_t)desc->n_world : plan.leaves.size();
+            for (size_t i = 0; i < n_leaves; i++) {
+                const PtShape& sh = desc->shapes[leaves[i].index];
+                const bool flat = sh.type == PT_SHAPE_RECT_XY || sh.type == PT_SHAPE_RECT_XZ || sh.type == PT_SHAPE_RECT_YZ;
+                if (!flat && sh.type != PT_SHAPE_BOX) continue;
+                if (sh.xform_count > 0) { wrapped = true; continue; }
+                if (sh.type == PT_SHAPE_RECT_XY) planes[2].push_back(sh.p[4]);
+                else if (sh.type == PT_SHAPE_RECT_XZ) planes[1].push_back(sh.p[4]);
+                else if (sh.type == PT_SHAPE_RECT_YZ) planes[0].push_back(sh.p[4]);
+                else for (int k = 0; k < 3; k++) { planes[k].push_back(sh.p[k]); planes[k].push_back(sh.p[3 + k]); }
+            }
+            std::vector<float> all;
+            for (int k = 0; k < 3; k++) {
+                std::sort(planes[k].begin(), planes[k].end());
+                planes[k].erase(std::unique(planes[k].begin(), planes[k].end()), planes[k].end());
+                all.insert(all.end(), planes[k].begin(), planes[k].end());
+                v.tree_plane_end[k] = (int32_t)all.size();
+            }
+            v.tree_wrapped = wrapped ? 1 : 0;
+            if (all.empty()) all.push_back(0.0f);             // never read: every run is empty
+            if (!upload(sc, all.data(), all.size(), &v.tree_planes, "upload tree planes")) { (void)hipFree(d_nodes); pt_scene_destroy(sc); return PT_ERR_HIP; }
         }
         if (built) {
             if (rc != PT_OK) { pt_scene_destroy(sc); return rc; }

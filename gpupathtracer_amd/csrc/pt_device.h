@@ -76,6 +76,9 @@ struct SceneView {
     const float*      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
     int32_t lbvh_prefix;        // world entries the LBVH stands for; the list walk continues from there
     int32_t reads_uv;           // the scene has an image texture (the only reader of a hit's uv)
+    const float*      tree_planes;  // plane coordinates of the un-wrapped rectangles and box faces in the LBVH, x planes, then y, then z
+    int32_t tree_plane_end[3];  // end of each axis' run in tree_planes
+    int32_t tree_wrapped;       // a wrapped rectangle or box is among the LBVH's leaves
     int32_t n_world, n_lights, lights_is_list, ambient_type;
     int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
     int32_t lbvh_cull;          // 1: prune by distance (no triangles in the tree)
@@ -674,13 +677,48 @@ struct LbvhWalk {
     float best;
     int best_id, best_face;
     bool any;
+    bool odd;            // a leaf accepted a hit whose t is NaN: only the in-order walk can say what that leads to
 };
+// Rectangles and boxes reject with comparisons that are all false for NaN, so they *accept* a ray
+// whose t comes out NaN: a ray lying in a rectangle's plane (direction component 0 and origin on
+// the plane: 0 / 0) "hits" that rectangle wherever it is, and so does any ray carrying NaN
+// (triangles likewise, for NaN input).  From then on the in-order walk's bound is NaN: every
+// later inclusive test passes, every sphere fails.  Neither a box test (the rectangle may be nowhere
+// near the ray) nor a comparison of candidates two at a time can reproduce that, so such rays do
+// not enter the tree; the caller walks the list in order for them.  The test is on the ray: a
+// non-finite component or a magnitude beyond 2^40 (with the tree's shapes bounded by 2^40 as well
+// -- checked when the tree is built -- no product in the triangle test can then overflow into
+// inf - inf), or a direction component that is exactly zero while the origin lies exactly in the
+// plane of one of the tree's rectangles or box faces on that axis (their coordinates are listed per
+// axis when the tree is built; exact zeros are not rare: a few primary rays per frame on the
+// horizon row).  A NaN accepted inside the tree all the same is noted (LbvhWalk::odd) and sends
+// the ray the same way.  Spheres never accept NaN.
+template <uint32_t F> struct accepts_nan { static constexpr bool value = (F & (F_RECT | F_BOX | F_TRIANGLE)) != 0; };
+constexpr float TREE_RAY_LIMIT = 0x1p40f;
+__device__ __forceinline__ bool on_a_tree_plane(const SceneView& sv, int axis, float o)
+{
+    if (sv.tree_wrapped) return true;                          // planes of wrapped shapes are not listed: assume the worst
+    for (int k = axis == 0 ? 0 : sv.tree_plane_end[axis - 1]; k < sv.tree_plane_end[axis]; k++)
+        if (sv.tree_planes[k] == o) return true;
+    return false;
+}
+__device__ __forceinline__ bool ray_may_enter_tree(const SceneView& sv, const Ray& r)
+{
+    const float s = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) + fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z);
+    if (!(s <= TREE_RAY_LIMIT)) return false;                  // also NaN and infinity
+    if (r.d.x != 0.0f && r.d.y != 0.0f && r.d.z != 0.0f) return true;
+    if (r.d.x == 0.0f && on_a_tree_plane(sv, 0, r.o.x)) return false;
+    if (r.d.y == 0.0f && on_a_tree_plane(sv, 1, r.o.y)) return false;
+    if (r.d.z == 0.0f && on_a_tree_plane(sv, 2, r.o.z)) return false;
+    return true;
+}
 __device__ __forceinline__ void lbvh_begin(const SceneView& sv, const Ray& r, float tmax, LbvhWalk& w)
 {
     w.inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     w.cur = sv.lbvh_root;
     w.sp = 0;
     w.any = false;
+    w.odd = false;
     w.best = tmax;
     w.best_id = -1; w.best_face = 0;
 }
@@ -709,6 +747,7 @@ __device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, flo
         const int id = ~w.cur;
         float t; int face;
         if (leaf_t<F>(sv, id, r, tmin, tmax, t, face)) {
+            if (accepts_nan<F>::value && t != t) w.odd = true;
             if (!w.any || list_order_better(sv, t, id, w.best, w.best_id)) { w.any = true; w.best = t; w.best_id = id; w.best_face = face; }
         }
     }
@@ -719,13 +758,13 @@ __device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, flo
 }
 template <uint32_t F>
 __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float tmin, float tmax,
-                                       float& t_out, int& id_out, int& face_out, int* stack)
+                                       float& t_out, int& id_out, int& face_out, bool& odd_out, int* stack)
 {
     int spill[LBVH_STACK - LBVH_LDS_STACK];
     LbvhWalk w;
     lbvh_begin(sv, r, tmax, w);
     while (!lbvh_step<F>(sv, r, tmin, tmax, w, stack, spill)) {}
-    t_out = w.best; id_out = w.best_id; face_out = w.best_face;
+    t_out = w.best; id_out = w.best_id; face_out = w.best_face; odd_out = w.odd;
     return w.any;
 }
 
@@ -862,10 +901,20 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
     if (F & F_LBVH) {
         // The tree stands for the first lbvh_prefix entries of the list (all of it when the list
         // holds shapes only); media and what follows them are walked in list order from there.
-        float t; int id, face;
-        if (lbvh_t<F>(sv, r, tmin, tmax, t, id, face, lbvh_stack)) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
-        if (!(F & (F_MEDIUM | F_REFBVH | F_IMAGE))) return any;
+        float t = 0; int id = 0, face = 0;
+        bool odd = false;
+        const bool enter = !accepts_nan<F>::value || ray_may_enter_tree(sv, r);
+        if (enter) {
+            if (lbvh_t<F>(sv, r, tmin, tmax, t, id, face, odd, lbvh_stack)) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
+        }
+        const bool in_order = accepts_nan<F>::value && (!enter || odd);      // see accepts_nan
+        if (!accepts_nan<F>::value) { if (!(F & (F_MEDIUM | F_REFBVH | F_IMAGE))) return any; }
+        else if (!(F & (F_MEDIUM | F_REFBVH | F_IMAGE))) { if (!in_order) return any; }
         first = sv.lbvh_prefix;
+        if (in_order) {
+            any = false; closest = tmax; first = 0;
+            h.id = PT_ID_MISS; h.face = 0; h.t = tmax;
+        }
         if ((F & F_IMAGE) && sv.reads_uv && any) {
             // Stale uv (see Hit): a plain sphere reports the uv of the last hit the in-order walk
             // accepted from a shape that writes uv.  Hits are accepted in decreasing t, so when the

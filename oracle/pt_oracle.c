@@ -1080,48 +1080,56 @@ int oracle_trace_records(const PtSceneDesc* sc, const PtRay* rays, size_t n, int
     return 0;
 }
 
-/* Camera rays of sample 0 of every pixel plus (optionally) the chain of secondary rays the
- * integrator follows from them: the ray set used for closest-hit parity checks.
- * Returns the number of rays written (<= capacity). */
-size_t oracle_record_rays(const PtSceneDesc* sc, int nx, int ny, int max_depth, PtRay* out, size_t capacity)
+/* Camera rays of the first `ns` samples of every pixel (or of pixel `only_pixel` alone when it is
+ * >= 0) plus the chain of secondary rays the integrator follows from them, the pixel's random
+ * stream running on from sample to sample as in render_pixel: the ray set used for closest-hit
+ * parity checks.  Returns the number of rays written (<= capacity). */
+size_t oracle_record_rays_ns(const PtSceneDesc* sc, int nx, int ny, int ns, int max_depth, int only_pixel, PtRay* out, size_t capacity)
 {
     size_t n = 0;
     for (int y = 0; y < ny && n < capacity; y++) {
         for (int x = 0; x < nx && n < capacity; x++) {
             unsigned i = (unsigned)((ny - y - 1) * nx + x);
+            if (only_pixel >= 0 && i != (unsigned)only_pixel) continue;
             pcg_t rng;
             pcg_seed(&rng, i);
-            float u = (x + pcg_rand(&rng)) / (float)nx;
-            float v = (y + pcg_rand(&rng)) / (float)ny;
-            ray_t cur = camera_get_ray(sc, u, v, &rng);
-            for (int depth = 0; depth < max_depth && n < capacity; depth++) {
-                PtRay* o = &out[n];
-                o->o[0] = cur.o.x; o->o[1] = cur.o.y; o->o[2] = cur.o.z;
-                o->d[0] = cur.d.x; o->d[1] = cur.d.y; o->d[2] = cur.d.z;
-                o->time = cur.time; o->seed = (uint32_t)n;
-                n++;
-                /* advance exactly as color() would, to get realistic secondary rays */
-                hitrec rec;
-                memset(&rec, 0, sizeof rec);
-                if (!world_hit(sc, &cur, 0.001f, FLT_MAX, &rec, &rng)) break;
-                scatter_t srec;
-                if (!material_scatter(sc, rec.mat, &cur, &rec, &srec, &rng)) break;
-                if (srec.is_specular) { cur = srec.specular_ray; continue; }
-                onb_t uvw;
-                onb_from_w(&uvw, rec.n);
-                v3 dir;
-                if (sc->n_lights > 0) {
-                    if (pcg_rand(&rng) < 0.5f) dir = lights_random(sc, rec.p, &rng);
-                    else dir = onb_local(&uvw, random_cosine_direction(&rng));
-                } else {
-                    dir = srec.cosine_pdf ? onb_local(&uvw, random_cosine_direction(&rng))
-                                          : random_to_unit_sphere(1, 1, &rng);
+            for (int s = 0; s < ns && n < capacity; s++) {
+                float u = (x + pcg_rand(&rng)) / (float)nx;
+                float v = (y + pcg_rand(&rng)) / (float)ny;
+                ray_t cur = camera_get_ray(sc, u, v, &rng);
+                for (int depth = 0; depth < max_depth && n < capacity; depth++) {
+                    PtRay* o = &out[n];
+                    o->o[0] = cur.o.x; o->o[1] = cur.o.y; o->o[2] = cur.o.z;
+                    o->d[0] = cur.d.x; o->d[1] = cur.d.y; o->d[2] = cur.d.z;
+                    o->time = cur.time; o->seed = (uint32_t)n;
+                    n++;
+                    /* advance exactly as color() would, to get realistic secondary rays */
+                    hitrec rec;
+                    memset(&rec, 0, sizeof rec);
+                    if (!world_hit(sc, &cur, 0.001f, FLT_MAX, &rec, &rng)) break;
+                    scatter_t srec;
+                    if (!material_scatter(sc, rec.mat, &cur, &rec, &srec, &rng)) break;
+                    if (srec.is_specular) { cur = srec.specular_ray; continue; }
+                    onb_t uvw;
+                    onb_from_w(&uvw, rec.n);
+                    v3 dir;
+                    if (sc->n_lights > 0) {
+                        if (pcg_rand(&rng) < 0.5f) dir = lights_random(sc, rec.p, &rng);
+                        else dir = onb_local(&uvw, random_cosine_direction(&rng));
+                    } else {
+                        dir = srec.cosine_pdf ? onb_local(&uvw, random_cosine_direction(&rng))
+                                              : random_to_unit_sphere(1, 1, &rng);
+                    }
+                    cur.o = rec.p; cur.d = dir;
                 }
-                cur.o = rec.p; cur.d = dir;
             }
         }
     }
     return n;
+}
+size_t oracle_record_rays(const PtSceneDesc* sc, int nx, int ny, int max_depth, PtRay* out, size_t capacity)
+{
+    return oracle_record_rays_ns(sc, nx, ny, 1, max_depth, -1, out, capacity);
 }
 
 /* Known-answer helpers. */

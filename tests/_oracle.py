@@ -21,6 +21,8 @@ class Oracle:
         lib.oracle_trace_records.argtypes = [P(A.PtSceneDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.oracle_record_rays.argtypes = [P(A.PtSceneDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.oracle_record_rays.restype = C.c_size_t
+        lib.oracle_record_rays_ns.argtypes = [P(A.PtSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.oracle_record_rays_ns.restype = C.c_size_t
         lib.oracle_pcg_stream.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
         lib.oracle_simple_rng_stream.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_void_p]
         lib.oracle_noise.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -58,6 +60,13 @@ class Oracle:
         from gpupathtracer_amd.api import RAY_DTYPE
         rays = np.zeros(capacity, RAY_DTYPE)
         n = self.lib.oracle_record_rays(desc.ptr, nx, ny, max_depth, rays.ctypes.data, capacity)
+        return rays[:n].copy()
+
+    def record_rays_ns(self, desc, nx, ny, ns, max_depth, capacity, only_pixel=-1):
+        """Rays of the first ns samples (the pixel's random stream running on), of one pixel if only_pixel >= 0."""
+        from gpupathtracer_amd.api import RAY_DTYPE
+        rays = np.zeros(capacity, RAY_DTYPE)
+        n = self.lib.oracle_record_rays_ns(desc.ptr, nx, ny, ns, max_depth, only_pixel, rays.ctypes.data, capacity)
         return rays[:n].copy()
 
     def median_filter(self, image, size=3):

@@ -809,6 +809,14 @@ def _random_world(rng, base):
     g.lists["media"], g.lists["world"] = media, entries
     g.lists["lights"] = []
     g.scalars["lights_is_list"] = 0
+    lamps = [i for i, sh in enumerate(shapes) if sh.type == abi.SHAPE_RECT_XZ and sh.xform_count == 0]
+    balls = [i for i, sh in enumerate(shapes) if sh.type == abi.SHAPE_SPHERE]
+    mode = int(rng.integers(0, 3))                             # no light shapes / one rectangle / a list of two
+    if mode == 1 and lamps:
+        g.lists["lights"] = [lamps[0]]
+    elif mode == 2 and lamps and balls:
+        g.lists["lights"] = [lamps[0], balls[-1]]
+        g.scalars["lights_is_list"] = 1
     return g
 
 
@@ -833,5 +841,5 @@ def test_random_worlds_match_the_oracle(oracle, seed):
         np.testing.assert_array_equal(ids_g, ids_o)
         np.testing.assert_array_equal(bits(t_g), bits(t_o))
         if ref is None:
-            ref = oracle.render(g, 40, 20, 3)
-        assert_bit_exact(sc.render(40, 20, 3), ref, "random world %d accel %d" % (seed, accel))
+            ref = oracle.render(g, 48, 24, 4)
+        assert_bit_exact(sc.render(48, 24, 4), ref, "random world %d accel %d" % (seed, accel))
