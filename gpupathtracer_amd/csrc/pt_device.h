@@ -548,6 +548,60 @@ __device__ __forceinline__ bool aabb_hit_inv(const float* bmin, const float* bma
     return true;
 }
 
+// BVH::hit (src/ptBVH.cu:45-74) evaluated node by node, for rays on which a leaf reports t = NaN
+// (a rectangle or box face accepts the 0/0 of a ray lying in its plane).  The reference keeps the
+// left child's record only when `left.t < right.t`; with NaN among the values that rule is not an
+// ordering (NaN loses on the left and wins on the right), so the winner depends on how the tree
+// pairs the leaves and a left-to-right scan no longer finds it.  This walk holds, per open node,
+// the finished left result while the right subtree is evaluated, then applies the rule itself.
+// It is the slow, exact path: refbvh_t falls back to it when it meets a NaN.
+// Masks whose shape tests can accept a NaN t (see ray_may_enter_tree).
+template <uint32_t F> struct accepts_nan { static constexpr bool value = (F & (F_RECT | F_BOX | F_TRIANGLE)) != 0; };
+constexpr int REFBVH_DEPTH = 48;
+template <uint32_t F>
+__device__ bool refbvh_by_node(const SceneView& sv, const Ray& r, const V3& inv, int root, float tmin, float tmax,
+                               float& t_out, int& id_out, int& face_out)
+{
+    int   link[REFBVH_DEPTH];                                      // the open nodes' right children
+    float lt[REFBVH_DEPTH];                                        // their finished left results
+    int   lid[REFBVH_DEPTH], lface[REFBVH_DEPTH];
+    uint64_t right_open = 0, left_hit = 0;                         // bit k: node k is in its right subtree / its left subtree hit
+    int sp = 0, cur = root;
+    while (true) {
+        bool hit = false; float t = 0.0f; int id = -1, face = 0;   // the result of the subtree at cur
+        bool finished = true;
+        if (cur < 0) {
+            hit = shape_t<F>(sv, ~cur, r, tmin, tmax, t, face);
+            id = ~cur;
+        } else {
+            const PtBvhNode* n = &sv.bvh_nodes[cur];
+            if (sp < REFBVH_DEPTH && aabb_hit_inv(n->bmin, n->bmax, r.o, inv, tmin, tmax)) {
+                link[sp] = n->right;
+                right_open &= ~(1ull << sp);
+                sp++;
+                cur = n->left;
+                finished = false;
+            }
+        }
+        while (finished) {
+            if (sp == 0) { t_out = t; id_out = id; face_out = face; return hit; }
+            const uint64_t bit = 1ull << (sp - 1);
+            if (!(right_open & bit)) {                             // that was the node's left subtree: keep it, go right
+                lt[sp - 1] = t; lid[sp - 1] = id; lface[sp - 1] = face;
+                left_hit = hit ? (left_hit | bit) : (left_hit & ~bit);
+                right_open |= bit;
+                cur = link[sp - 1];
+                finished = false;
+            } else {                                               // both children known: src/ptBVH.cu:56-70
+                const bool hl = (left_hit & bit) != 0;
+                if (hl && (!hit || lt[sp - 1] < t)) { t = lt[sp - 1]; id = lid[sp - 1]; face = lface[sp - 1]; }
+                hit = hit || hl;
+                sp--;
+            }
+        }
+    }
+}
+
 // BVH::hit (src/ptBVH.cu:45-74) without recursion.  The reference visits both children of every
 // node whose box the ray meets within the caller's [tmin,tmax] (the range never shrinks inside
 // the tree) and keeps the left result only when it is strictly nearer; the winner over a subtree
@@ -570,7 +624,7 @@ __device__ __forceinline__ bool refbvh_t(const SceneView& sv, int bvh_index, con
     int spill[REFBVH_STACK - TREE_LDS_STACK];
     int sp = 0;
     int cur = b.root;
-    bool any = false, done = false;
+    bool any = false, done = false, nan_seen = false;
     float best = 0.0f;
     while (true) {
         while (!done && cur >= 0) {                                // inner nodes
@@ -592,11 +646,13 @@ __device__ __forceinline__ bool refbvh_t(const SceneView& sv, int bvh_index, con
         float t; int face;                                         // a leaf
         if (shape_t<F>(sv, ~cur, r, tmin, tmax, t, face)) {
             if (!any || !(best < t)) { any = true; best = t; id_out = ~cur; face_out = face; }
+            if (accepts_nan<F>::value && t != t) nan_seen = true;
         }
         if (sp == 0) break;
         --sp;
         cur = (sp < TREE_LDS_STACK) ? stack[sp * 64] : spill[sp - TREE_LDS_STACK];
     }
+    if (accepts_nan<F>::value && nan_seen) return refbvh_by_node<F>(sv, r, inv, b.root, tmin, tmax, t_out, id_out, face_out);
     t_out = best;
     return any;
 }
@@ -693,7 +749,6 @@ struct LbvhWalk {
 // axis when the tree is built; exact zeros are not rare: a few primary rays per frame on the
 // horizon row).  A NaN accepted inside the tree all the same is noted (LbvhWalk::odd) and sends
 // the ray the same way.  Spheres never accept NaN.
-template <uint32_t F> struct accepts_nan { static constexpr bool value = (F & (F_RECT | F_BOX | F_TRIANGLE)) != 0; };
 constexpr float TREE_RAY_LIMIT = 0x1p40f;
 __device__ __forceinline__ bool on_a_tree_plane(const SceneView& sv, int axis, float o)
 {

@@ -709,6 +709,39 @@ def test_lbvh_keeps_the_reference_trees_tie_rule(oracle):
         assert winners == ({1} if order == "entry first" else {2}), (order, winners)
 
 
+@pytest.mark.parametrize("which", ["trimesh", "final"])
+def test_rays_lying_in_a_plane_of_the_tree(oracle, which):
+    """A ray with a zero direction component whose origin lies exactly in a rectangle's (or box
+    face's) plane gets t = 0/0 there, and the reference's comparisons accept NaN: the in-order walk
+    then reports that entry wherever it is and keeps a NaN bound.  A tree cannot reproduce that, so
+    such rays go round it; the same rays a hair off the plane, or with the zero on another axis,
+    stay in the tree.  Both kinds must match the oracle."""
+    if which == "trimesh":
+        d = pt.trimesh_scene(12, 1.0)
+        planes = [0.0, 555.0, 554.0, -0.0, 213.0, 100.0, 554.00006]
+        lo, hi = 0, 555
+    else:
+        d = pt.builtin_scene("final", 1.0)                    # boxes of a reference BVH: face planes at multiples of 100, and random heights
+        planes = [0.0, 100.0, -1000.0, -900.0, 554.0, 123.0, 147.0, 412.0] + [float(np.float32(d.c.shapes[i].p[4])) for i in range(0, 40, 7)]
+        lo, hi = -1000, 1000
+    d.c.accel = abi.ACCEL_LBVH
+    sc = pt.Scene(d)
+    rng = np.random.default_rng(77)
+    rays = random_rays(rng, 6000, lo, hi)
+    n = len(rays)
+    axis = rng.integers(0, 3, n)
+    rays["d"][np.arange(n), axis] = np.where(rng.random(n) < 0.5, 0.0, -0.0).astype(np.float32)
+    on_plane = rng.random(n) < 0.7
+    rays["o"][np.arange(n)[on_plane], axis[on_plane]] = rng.choice(np.array(planes, np.float32), on_plane.sum())
+    two = rng.random(n) < 0.2                                  # a second zero component
+    rays["d"][np.arange(n)[two], (axis[two] + 1) % 3] = 0.0
+    ids_o, t_o = oracle.trace_closest(d, rays)
+    ids_g, t_g = sc.trace_closest(rays)
+    assert np.isnan(t_o).sum() > 100 and (~np.isnan(t_o) & (ids_o >= 0)).sum() > 100
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+
+
 def _random_world(rng, base):
     """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
     rectangles (some flipped, some wrapped boxes), an optional reference BVH at the head of the
