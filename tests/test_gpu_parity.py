@@ -709,7 +709,7 @@ def test_lbvh_keeps_the_reference_trees_tie_rule(oracle):
         assert winners == ({1} if order == "entry first" else {2}), (order, winners)
 
 
-@pytest.mark.parametrize("which", ["trimesh", "final"])
+@pytest.mark.parametrize("which", ["trimesh", "final", "cornell", "cornell_tree"])
 def test_rays_lying_in_a_plane_of_the_tree(oracle, which):
     """A ray with a zero direction component whose origin lies exactly in a rectangle's (or box
     face's) plane gets t = 0/0 there, and the reference's comparisons accept NaN: the in-order walk
@@ -720,11 +720,16 @@ def test_rays_lying_in_a_plane_of_the_tree(oracle, which):
         d = pt.trimesh_scene(12, 1.0)
         planes = [0.0, 555.0, 554.0, -0.0, 213.0, 100.0, 554.00006]
         lo, hi = 0, 555
+    elif which.startswith("cornell"):                          # the signature walk (list) and the tree with wrapped boxes
+        d = pt.builtin_scene("cornell", 1.0)
+        planes = [0.0, 555.0, 554.0, -0.0, 165.0, 330.0, 100.0]
+        lo, hi = 0, 555
     else:
         d = pt.builtin_scene("final", 1.0)                    # boxes of a reference BVH: face planes at multiples of 100, and random heights
         planes = [0.0, 100.0, -1000.0, -900.0, 554.0, 123.0, 147.0, 412.0] + [float(np.float32(d.c.shapes[i].p[4])) for i in range(0, 40, 7)]
         lo, hi = -1000, 1000
-    d.c.accel = abi.ACCEL_LBVH
+    if which != "cornell":
+        d.c.accel = abi.ACCEL_LBVH
     sc = pt.Scene(d)
     rng = np.random.default_rng(77)
     rays = random_rays(rng, 6000, lo, hi)
