@@ -252,8 +252,16 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
             bool any = w.any;
             if (any) { h.t = w.best; h.id = w.best_id; h.face = w.best_face; }
-            if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray)))       // see accepts_nan: the list, in order
-                any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+            if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray))) {     // see accepts_nan: the list, in order
+                float t = 0; int id = 0, face = 0;
+                const int got = lbvh_in_plane_t<F>(sv, st.ray, 0.001f, FLT_MAX, t, id, face);
+                if (got < 0) any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+                else {
+                    any = got > 0;
+                    h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX;
+                    if (any) { h.t = t; h.id = id; h.face = face; }
+                }
+            }
             bool ended;
             if (any) {
                 ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
@@ -713,7 +721,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     // medium (or wrapped BVH): the shapes and the BVHs' leaves of that leading run become the
     // tree's leaves and the walk continues in list order behind it (lbvh_plan).
     v.lbvh_order = nullptr; v.lbvh_group = nullptr; v.ref_leaf_gate = nullptr;
-    v.tree_planes = nullptr; v.tree_plane_end[0] = v.tree_plane_end[1] = v.tree_plane_end[2] = 0; v.tree_wrapped = 0;
+    v.tree_planes = nullptr; v.tree_plane_first = nullptr; v.tree_plane_members = nullptr; v.tree_plane_end[0] = v.tree_plane_end[1] = v.tree_plane_end[2] = 0; v.tree_wrapped = 0;
     v.lbvh_prefix = desc->n_world;
     v.reads_uv = (mask & F_IMAGE) ? 1 : 0;
     bool tree_sized = true;                                    // see ray_may_enter_tree: shapes within 2^40
@@ -747,30 +755,42 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         }
         if (built && rc == PT_OK) {
             // plane coordinates of the tree's un-wrapped rectangles and box faces, per axis (ray_may_enter_tree)
-            std::vector<float> planes[3];
+            std::vector<std::pair<float, int32_t>> on_axis[3];      // (plane, shape)
             bool wrapped = false;
             const PtObject* leaves = in_table_order ? desc->world : plan.leaves.data();
             const size_t n_leaves = in_table_order ? (size_t)desc->n_world : plan.leaves.size();
             for (size_t i = 0; i < n_leaves; i++) {
-                const PtShape& sh = desc->shapes[leaves[i].index];
+                const int32_t id = leaves[i].index;
+                const PtShape& sh = desc->shapes[id];
                 const bool flat = sh.type == PT_SHAPE_RECT_XY || sh.type == PT_SHAPE_RECT_XZ || sh.type == PT_SHAPE_RECT_YZ;
                 if (!flat && sh.type != PT_SHAPE_BOX) continue;
                 if (sh.xform_count > 0) { wrapped = true; continue; }
-                if (sh.type == PT_SHAPE_RECT_XY) planes[2].push_back(sh.p[4]);
-                else if (sh.type == PT_SHAPE_RECT_XZ) planes[1].push_back(sh.p[4]);
-                else if (sh.type == PT_SHAPE_RECT_YZ) planes[0].push_back(sh.p[4]);
-                else for (int k = 0; k < 3; k++) { planes[k].push_back(sh.p[k]); planes[k].push_back(sh.p[3 + k]); }
+                auto put = [&](int axis, float k) { on_axis[axis].push_back({ k == 0.0f ? 0.0f : k, id }); };    // -0 and +0 are one plane
+                if (sh.type == PT_SHAPE_RECT_XY) put(2, sh.p[4]);
+                else if (sh.type == PT_SHAPE_RECT_XZ) put(1, sh.p[4]);
+                else if (sh.type == PT_SHAPE_RECT_YZ) put(0, sh.p[4]);
+                else for (int k = 0; k < 3; k++) { put(k, sh.p[k]); put(k, sh.p[3 + k]); }
             }
             std::vector<float> all;
+            std::vector<int32_t> first, members;
             for (int k = 0; k < 3; k++) {
-                std::sort(planes[k].begin(), planes[k].end());
-                planes[k].erase(std::unique(planes[k].begin(), planes[k].end()), planes[k].end());
-                all.insert(all.end(), planes[k].begin(), planes[k].end());
+                std::sort(on_axis[k].begin(), on_axis[k].end());
+                on_axis[k].erase(std::unique(on_axis[k].begin(), on_axis[k].end()), on_axis[k].end());
+                for (size_t i = 0; i < on_axis[k].size(); i++) {
+                    if (i == 0 || on_axis[k][i].first != on_axis[k][i - 1].first) { all.push_back(on_axis[k][i].first); first.push_back((int32_t)members.size()); }
+                    members.push_back(on_axis[k][i].second);
+                }
                 v.tree_plane_end[k] = (int32_t)all.size();
             }
+            first.push_back((int32_t)members.size());
             v.tree_wrapped = wrapped ? 1 : 0;
             if (all.empty()) all.push_back(0.0f);             // never read: every run is empty
-            if (!upload(sc, all.data(), all.size(), &v.tree_planes, "upload tree planes")) { (void)hipFree(d_nodes); pt_scene_destroy(sc); return PT_ERR_HIP; }
+            if (members.empty()) members.push_back(0);
+            if (!(upload(sc, all.data(), all.size(), &v.tree_planes, "upload tree planes") &&
+                  upload(sc, first.data(), first.size(), &v.tree_plane_first, "upload tree plane runs") &&
+                  upload(sc, members.data(), members.size(), &v.tree_plane_members, "upload tree plane members"))) {
+                (void)hipFree(d_nodes); pt_scene_destroy(sc); return PT_ERR_HIP;
+            }
         }
         if (built) {
             if (rc != PT_OK) { pt_scene_destroy(sc); return rc; }

@@ -78,6 +78,8 @@ struct SceneView {
     int32_t reads_uv;           // the scene has an image texture (the only reader of a hit's uv)
     const float*      tree_planes;  // plane coordinates of the un-wrapped rectangles and box faces in the LBVH, x planes, then y, then z
     int32_t tree_plane_end[3];  // end of each axis' run in tree_planes
+    const int32_t*    tree_plane_first;    // per plane (+1): start of its run in tree_plane_members
+    const int32_t*    tree_plane_members;  // the shapes that have a rectangle in that plane
     int32_t tree_wrapped;       // a wrapped rectangle or box is among the LBVH's leaves
     int32_t n_world, n_lights, lights_is_list, ambient_type;
     int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
@@ -823,6 +825,90 @@ __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float 
     return w.any;
 }
 
+// The in-order walk's answer for a finite ray with exactly one zero direction component that lies
+// in a plane of the tree's rectangles or box faces, without walking the list (a 2 M-triangle list
+// takes a lane seconds, and a Cornell-like room sends about one such ray per 10^8 paths: a wall
+// point at exactly the lamp's height sampling the lamp).  Which entries the in-order walk accepts
+// depends on the running bound, but an entry that can be accepted under *some* bound is either
+// one of the shapes with a rectangle in that plane (t = 0/0 there: accepted wherever they are;
+// listed per plane when the tree is built) or a shape the ray really crosses, and those are the
+// leaves an un-pruned tree walk reaches and whose test passes under the most permissive bound
+// (NaN for the kinds that reject with `t > bound`, +inf for spheres, which reject a NaN bound).
+// Those few candidates are then tested in list order with the walk's real, running bound: every
+// other entry would have been rejected whatever the bound, so this is the walk's result.
+// Returns 1 (hit) / 0 (miss), or -1 when the ray or the tree is not of that kind (wrapped
+// rectangles or boxes in the tree, several zero components, non-finite values) or the candidates
+// do not fit: then the caller walks the list.
+constexpr int GATHER_MAX = 24;
+__device__ __forceinline__ int list_place(const SceneView& sv, int id) { return sv.lbvh_order ? sv.lbvh_order[id] : id; }
+template <uint32_t F>
+__device__ int lbvh_in_plane_t(const SceneView& sv, const Ray& r, float tmin, float tmax, float& t_out, int& id_out, int& face_out)
+{
+    if (sv.tree_wrapped || sv.tree_plane_first == nullptr) return -1;
+    const float s = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) + fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z);
+    if (!(s <= TREE_RAY_LIMIT)) return -1;
+    if ((r.d.x == 0.0f) + (r.d.y == 0.0f) + (r.d.z == 0.0f) != 1) return -1;
+    const int axis = r.d.x == 0.0f ? 0 : (r.d.y == 0.0f ? 1 : 2);
+    const float o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
+    int cand[GATHER_MAX];
+    int n = 0;
+    for (int k = axis == 0 ? 0 : sv.tree_plane_end[axis - 1]; k < sv.tree_plane_end[axis]; k++) {
+        if (!(sv.tree_planes[k] == o)) continue;
+        for (int m = sv.tree_plane_first[k]; m < sv.tree_plane_first[k + 1]; m++) {
+            if (n == GATHER_MAX) return -1;
+            cand[n++] = sv.tree_plane_members[m];
+        }
+    }
+    const int n_in_plane = n;
+    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    int pending[LBVH_STACK];
+    int sp = 0, cur = sv.lbvh_root;
+    while (true) {
+        if (cur >= 0) {
+            const LbvhNode* nd = &sv.lbvh[cur];
+            float tl, tr;
+            const bool hl = slab(nd->lmin, nd->lmax, r.o, inv, tmin, INFINITY, tl);
+            const bool hr = slab(nd->rmin, nd->rmax, r.o, inv, tmin, INFINITY, tr);
+            if (hl && hr) {
+                if (sp == LBVH_STACK) return -1;
+                pending[sp++] = nd->right;
+                cur = nd->left;
+                continue;
+            }
+            if (hl) { cur = nd->left; continue; }
+            if (hr) { cur = nd->right; continue; }
+        } else {
+            const int id = ~cur;
+            float t; int face;
+            const float loosest = inclusive_kind(sv.shapes[id].type) ? __builtin_nanf("") : INFINITY;
+            if (leaf_t<F>(sv, id, r, tmin, loosest, t, face)) {
+                bool known = false;
+                for (int c = 0; c < n_in_plane; c++) known = known || cand[c] == id;
+                if (!known) {
+                    if (n == GATHER_MAX) return -1;
+                    cand[n++] = id;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = pending[--sp];
+    }
+    for (int a = 1; a < n; a++) {                                  // into list order
+        const int id = cand[a], place = list_place(sv, id);
+        int b = a;
+        while (b > 0 && list_place(sv, cand[b - 1]) > place) { cand[b] = cand[b - 1]; b--; }
+        cand[b] = id;
+    }
+    bool any = false;
+    float closest = tmax;
+    for (int c = 0; c < n; c++) {
+        float t; int face;
+        if (leaf_t<F>(sv, cand[c], r, tmin, closest, t, face)) { any = true; closest = t; id_out = cand[c]; face_out = face; }
+    }
+    t_out = closest;
+    return any ? 1 : 0;
+}
+
 // ---- world signatures -------------------------------------------------------------------------------
 // A world list whose sequence of entry kinds is known at compile time is walked by straight-line
 // code: entry k of the list is addressed with a constant, so every scene value the walk reads is
@@ -969,6 +1055,13 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
         if (in_order) {
             any = false; closest = tmax; first = 0;
             h.id = PT_ID_MISS; h.face = 0; h.t = tmax;
+            if (!(F & (F_REFBVH | F_IMAGE))) {                   // the tree's part of the list from a few candidates, if the ray is of that kind
+                const int got = lbvh_in_plane_t<F>(sv, r, tmin, tmax, t, id, face);
+                if (got >= 0) {
+                    first = sv.lbvh_prefix;
+                    if (got > 0) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
+                }
+            }
         }
         if ((F & F_IMAGE) && sv.reads_uv && any) {
             // Stale uv (see Hit): a plain sphere reports the uv of the last hit the in-order walk

@@ -747,6 +747,25 @@ def test_rays_lying_in_a_plane_of_the_tree(oracle, which):
     np.testing.assert_array_equal(bits(t_g), bits(t_o))
 
 
+@pytest.mark.parametrize("schedule", [abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL])
+def test_render_with_every_primary_ray_in_the_lamps_plane(oracle, schedule):
+    """A camera at the lamp's height whose `vertical` vector is zero: every primary ray has
+    d.y == 0 and o.y == 554, the XZ lamp's plane, so the lamp (and, after its NaN bound, whatever
+    the list holds behind it) is 'hit' from anywhere.  The tree schedules answer these rays from a
+    few candidates instead of the list; the frame must still be the in-order walk's."""
+    d = pt.trimesh_scene(12, 1.0)
+    d.c.accel = abi.ACCEL_LBVH
+    d.c.camera[1] = 554.0                                      # origin.y
+    d.c.camera[4] = 554.0                                      # lowerLeftCorner.y
+    for k in (9, 10, 11):
+        d.c.camera[k] = 0.0                                    # vertical
+    sc = pt.Scene(d)
+    got = sc.render(40, 6, 8, schedule=schedule)
+    assert_bit_exact(got, oracle.render(d, 40, 6, 8), "in-plane camera")
+    rays = oracle.record_rays(d, 40, 6, 2, 4000)
+    assert ((rays["d"][:, 1] == 0) & (rays["o"][:, 1] == 554.0)).sum() >= 200
+
+
 def _random_world(rng, base):
     """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
     rectangles (some flipped, some wrapped boxes), an optional reference BVH at the head of the
