@@ -253,13 +253,13 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             bool any = w.any;
             if (any) { h.t = w.best; h.id = w.best_id; h.face = w.best_face; }
             if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray))) {     // see accepts_nan: the list, in order
-                float t = 0; int id = 0, face = 0;
-                const int got = lbvh_in_plane_t<F>(sv, st.ray, 0.001f, FLT_MAX, t, id, face);
-                if (got < 0) any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+                const InPlaneHit got = lbvh_in_plane_t<F>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z, st.ray.d.x, st.ray.d.y, st.ray.d.z,
+                                                          st.ray.time, 0.001f, FLT_MAX);
+                if (got.found < 0) any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
                 else {
-                    any = got > 0;
+                    any = got.found > 0;
                     h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX;
-                    if (any) { h.t = t; h.id = id; h.face = face; }
+                    if (any) { h.t = got.t; h.id = got.id; h.face = got.face; }
                 }
             }
             bool ended;
@@ -810,6 +810,13 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         sc->variant = V_CORNELL_WORLD;
     }
     if (sc->variant < 0) { pt::set_error("pt_scene_create: no kernel specialisation covers this scene"); pt_scene_destroy(sc); return PT_ERR_UNSUPPORTED; }
+    {
+        void* copy = nullptr;                                  // the view itself, for device code kept out of line
+        if (!hip_ok(hipMalloc(&copy, sizeof(SceneView)), "hipMalloc(scene view)")) { pt_scene_destroy(sc); return PT_ERR_OOM; }
+        sc->allocs.push_back(copy);
+        v.self = static_cast<const SceneView*>(copy);
+        if (!hip_ok(hipMemcpy(copy, &v, sizeof(SceneView), hipMemcpyHostToDevice), "hipMemcpy(scene view)")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+    }
     {
         void* ctr = nullptr;
         if (!hip_ok(hipMalloc(&ctr, 256), "hipMalloc(slot counter)")) { pt_scene_destroy(sc); return PT_ERR_OOM; }

@@ -80,6 +80,7 @@ struct SceneView {
     int32_t tree_plane_end[3];  // end of each axis' run in tree_planes
     const int32_t*    tree_plane_first;    // per plane (+1): start of its run in tree_plane_members
     const int32_t*    tree_plane_members;  // the shapes that have a rectangle in that plane
+    const SceneView*  self;                // this view in device memory, for code kept out of line
     int32_t tree_wrapped;       // a wrapped rectangle or box is among the LBVH's leaves
     int32_t n_world, n_lights, lights_is_list, ambient_type;
     int32_t lbvh_root;          // >= 0 inner node, < 0 ~shape, when an LBVH is in use
@@ -841,13 +842,21 @@ __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float 
 // do not fit: then the caller walks the list.
 constexpr int GATHER_MAX = 24;
 __device__ __forceinline__ int list_place(const SceneView& sv, int id) { return sv.lbvh_order ? sv.lbvh_order[id] : id; }
+// Kept out of line (arguments and result by value, the scene through its copy in device memory):
+// inlined, this rare path cost the kernels around it registers and spills.
+struct InPlaneHit { int found; float t; int id, face; };
 template <uint32_t F>
-__device__ int lbvh_in_plane_t(const SceneView& sv, const Ray& r, float tmin, float tmax, float& t_out, int& id_out, int& face_out)
+__device__ __attribute__((noinline)) InPlaneHit lbvh_in_plane_t(const SceneView* view, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                                float time, float tmin, float tmax)
 {
-    if (sv.tree_wrapped || sv.tree_plane_first == nullptr) return -1;
+    const SceneView& sv = *view;
+    Ray r; r.o = mk(ox, oy, oz); r.d = mk(dx, dy, dz); r.time = time;
+    InPlaneHit out; out.found = -1; out.t = tmax; out.id = -1; out.face = 0;
+    int id_out = -1, face_out = 0;
+    if (sv.tree_wrapped || sv.tree_plane_first == nullptr) return out;
     const float s = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) + fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z);
-    if (!(s <= TREE_RAY_LIMIT)) return -1;
-    if ((r.d.x == 0.0f) + (r.d.y == 0.0f) + (r.d.z == 0.0f) != 1) return -1;
+    if (!(s <= TREE_RAY_LIMIT)) return out;
+    if ((r.d.x == 0.0f) + (r.d.y == 0.0f) + (r.d.z == 0.0f) != 1) return out;
     const int axis = r.d.x == 0.0f ? 0 : (r.d.y == 0.0f ? 1 : 2);
     const float o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
     int cand[GATHER_MAX];
@@ -855,7 +864,7 @@ __device__ int lbvh_in_plane_t(const SceneView& sv, const Ray& r, float tmin, fl
     for (int k = axis == 0 ? 0 : sv.tree_plane_end[axis - 1]; k < sv.tree_plane_end[axis]; k++) {
         if (!(sv.tree_planes[k] == o)) continue;
         for (int m = sv.tree_plane_first[k]; m < sv.tree_plane_first[k + 1]; m++) {
-            if (n == GATHER_MAX) return -1;
+            if (n == GATHER_MAX) return out;
             cand[n++] = sv.tree_plane_members[m];
         }
     }
@@ -870,7 +879,7 @@ __device__ int lbvh_in_plane_t(const SceneView& sv, const Ray& r, float tmin, fl
             const bool hl = slab(nd->lmin, nd->lmax, r.o, inv, tmin, INFINITY, tl);
             const bool hr = slab(nd->rmin, nd->rmax, r.o, inv, tmin, INFINITY, tr);
             if (hl && hr) {
-                if (sp == LBVH_STACK) return -1;
+                if (sp == LBVH_STACK) return out;
                 pending[sp++] = nd->right;
                 cur = nd->left;
                 continue;
@@ -885,7 +894,7 @@ __device__ int lbvh_in_plane_t(const SceneView& sv, const Ray& r, float tmin, fl
                 bool known = false;
                 for (int c = 0; c < n_in_plane; c++) known = known || cand[c] == id;
                 if (!known) {
-                    if (n == GATHER_MAX) return -1;
+                    if (n == GATHER_MAX) return out;
                     cand[n++] = id;
                 }
             }
@@ -905,8 +914,8 @@ __device__ int lbvh_in_plane_t(const SceneView& sv, const Ray& r, float tmin, fl
         float t; int face;
         if (leaf_t<F>(sv, cand[c], r, tmin, closest, t, face)) { any = true; closest = t; id_out = cand[c]; face_out = face; }
     }
-    t_out = closest;
-    return any ? 1 : 0;
+    out.found = any ? 1 : 0; out.t = closest; out.id = id_out; out.face = face_out;
+    return out;
 }
 
 // ---- world signatures -------------------------------------------------------------------------------
@@ -1056,10 +1065,10 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
             any = false; closest = tmax; first = 0;
             h.id = PT_ID_MISS; h.face = 0; h.t = tmax;
             if (!(F & (F_REFBVH | F_IMAGE))) {                   // the tree's part of the list from a few candidates, if the ray is of that kind
-                const int got = lbvh_in_plane_t<F>(sv, r, tmin, tmax, t, id, face);
-                if (got >= 0) {
+                const InPlaneHit got = lbvh_in_plane_t<F>(sv.self, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.time, tmin, tmax);
+                if (got.found >= 0) {
                     first = sv.lbvh_prefix;
-                    if (got > 0) { any = true; closest = t; h.t = t; h.id = id; h.face = face; }
+                    if (got.found > 0) { any = true; closest = got.t; h.t = got.t; h.id = got.id; h.face = got.face; }
                 }
             }
         }
