@@ -768,7 +768,7 @@ def test_render_with_every_primary_ray_in_the_lamps_plane(oracle, schedule):
 
 def _random_world(rng, base):
     """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
-    rectangles (some flipped, some wrapped boxes), an optional reference BVH at the head of the
+    rectangles (some flipped, some wrapped boxes), triangles, an optional reference BVH at the head of the
     list or later in it (median splits, boxes = unions of the leaves' bounds), optional media."""
     from tests._desc_tools import OwnedDesc
     from gpupathtracer_amd import _abi as A
@@ -795,8 +795,12 @@ def _random_world(rng, base):
     for _ in range(n):
         c = rng.uniform(-50, 50, 3).astype(np.float32)
         r = np.float32(rng.uniform(1, 12))
-        k = rng.integers(0, 6)
-        if k == 0:
+        k = rng.integers(0, 7)
+        if k == 6:
+            v = (c[None, :] + rng.uniform(-12, 12, (3, 3))).astype(np.float32)
+            i = add(abi.SHAPE_TRIANGLE, list(v.reshape(-1)))
+            plain.append((i, 1, v.min(0) - np.float32(1e-3), v.max(0) + np.float32(1e-3)))
+        elif k == 0:
             i = add(abi.SHAPE_SPHERE, [c[0], c[1], c[2], r])
             plain.append((i, 0, c - r, c + r))
         elif k == 1:
