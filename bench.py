@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mpaths/s, whole job, Cornell box 1024x1024 at 4096 spp (BASELINE.json
-configs[2]), tile-sharded over N MI355X of one node.
+"""Headline benchmark: Mpaths/s, whole job, Cornell box 1024x1024 at 4096 spp, tile-sharded over
+N MI355X of one node.
 
 One process per GPU (the driver starts N of them through torch.distributed.run).  A "step" is one
 complete render of the frame: every rank traces its 8x8-tile shard of the image with the scene

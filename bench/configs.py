@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The other BASELINE configurations on one GPU (the headline, Cornell 1024^2 x 4096, is bench.py):
+"""The other benchmark configurations on one GPU (the headline, Cornell 1024^2 x 4096, is bench.py):
 RTIOW 1920x1080 with the LBVH, the RTNW final scene, and the 2M-triangle height field in the
 Cornell enclosure.  Prints one JSON object per configuration; --quick cuts samples for a smoke run."""
 import argparse
