@@ -826,7 +826,7 @@ __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float 
     return w.any;
 }
 
-// The in-order walk's answer for a finite ray with exactly one zero direction component that lies
+// The in-order walk's answer for a finite ray with one or two zero direction components that lies
 // in a plane of the tree's rectangles or box faces, without walking the list (a 2 M-triangle list
 // takes a lane seconds, and a Cornell-like room sends about one such ray per 10^8 paths: a wall
 // point at exactly the lamp's height sampling the lamp).  Which entries the in-order walk accepts
@@ -838,7 +838,7 @@ __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float 
 // Those few candidates are then tested in list order with the walk's real, running bound: every
 // other entry would have been rejected whatever the bound, so this is the walk's result.
 // Returns 1 (hit) / 0 (miss), or -1 when the ray or the tree is not of that kind (wrapped
-// rectangles or boxes in the tree, several zero components, non-finite values) or the candidates
+// rectangles or boxes in the tree, a zero direction, non-finite values) or the candidates
 // do not fit: then the caller walks the list.
 constexpr int GATHER_MAX = 24;
 __device__ __forceinline__ int list_place(const SceneView& sv, int id) { return sv.lbvh_order ? sv.lbvh_order[id] : id; }
@@ -856,16 +856,24 @@ __device__ __attribute__((noinline)) InPlaneHit lbvh_in_plane_t(const SceneView*
     if (sv.tree_wrapped || sv.tree_plane_first == nullptr) return out;
     const float s = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) + fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z);
     if (!(s <= TREE_RAY_LIMIT)) return out;
-    if ((r.d.x == 0.0f) + (r.d.y == 0.0f) + (r.d.z == 0.0f) != 1) return out;
-    const int axis = r.d.x == 0.0f ? 0 : (r.d.y == 0.0f ? 1 : 2);
-    const float o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
+    const int zeros = (r.d.x == 0.0f) + (r.d.y == 0.0f) + (r.d.z == 0.0f);
+    if (zeros < 1 || zeros > 2) return out;                        // a zero direction makes every test NaN or infinite
     int cand[GATHER_MAX];
     int n = 0;
-    for (int k = axis == 0 ? 0 : sv.tree_plane_end[axis - 1]; k < sv.tree_plane_end[axis]; k++) {
-        if (!(sv.tree_planes[k] == o)) continue;
-        for (int m = sv.tree_plane_first[k]; m < sv.tree_plane_first[k + 1]; m++) {
-            if (n == GATHER_MAX) return out;
-            cand[n++] = sv.tree_plane_members[m];
+    for (int axis = 0; axis < 3; axis++) {
+        const float dk = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
+        const float o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
+        if (dk != 0.0f) continue;
+        for (int k = axis == 0 ? 0 : sv.tree_plane_end[axis - 1]; k < sv.tree_plane_end[axis]; k++) {
+            if (!(sv.tree_planes[k] == o)) continue;
+            for (int m = sv.tree_plane_first[k]; m < sv.tree_plane_first[k + 1]; m++) {
+                const int id = sv.tree_plane_members[m];
+                bool known = false;                                // a box can have faces in the planes of both axes
+                for (int c = 0; c < n; c++) known = known || cand[c] == id;
+                if (known) continue;
+                if (n == GATHER_MAX) return out;
+                cand[n++] = id;
+            }
         }
     }
     const int n_in_plane = n;

@@ -905,6 +905,8 @@ def test_random_worlds_match_the_oracle(oracle, seed):
                 plane = sh.p[4]
             rays["o"][i, axis] = plane
             rays["d"][i, axis] = 0.0 if rng.random() < 0.5 else -0.0
+            if rng.random() < 0.3:                                 # axis-parallel: the direction the reference's base-class light gives
+                rays["d"][i, (axis + 1 + int(rng.integers(0, 2))) % 3] = 0.0
     ref = None
     for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
         g.scalars["accel"] = accel
