@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""The headline frame against the oracle at full size: Cornell 1024x1024 at 4096 spp, every channel of
+every pixel compared bit for bit.  Two minutes of host time on sixteen threads, so it is a script and
+not part of the collected tests:
+
+    python tests/full_frame_check.py [--scene cornell] [--size 1024] [--spp 4096] [--out result.json]
+
+The oracle renders the frame in tile shards (progress line after each); the GPU renders it in one launch."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gpupathtracer_amd as pt                     # noqa: E402
+from tests import _oracle                          # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=4096)
+    ap.add_argument("--shards", type=int, default=32)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    oracle = _oracle.load()
+    pt.set_device(0)
+    d = pt.builtin_scene(a.scene, 1.0)
+    sc = pt.Scene(d)
+    t0 = time.perf_counter()
+    gpu = sc.render(a.size, a.size, a.spp)
+    gpu_s = time.perf_counter() - t0
+    print("gpu frame in %.2f s (kernel %.1f ms)" % (gpu_s, sc.stats().kernel_ms), flush=True)
+    cpu = np.zeros_like(gpu)
+    t0 = time.perf_counter()
+    for k in range(a.shards):
+        cpu += oracle.render(d, a.size, a.size, a.spp, shard_index=k, shard_count=a.shards, threads=a.threads)
+        print("oracle shard %d/%d, %.0f s" % (k + 1, a.shards, time.perf_counter() - t0), flush=True)
+    cpu_s = time.perf_counter() - t0
+    same = gpu.view(np.uint32) == cpu.view(np.uint32)
+    res = {"scene": a.scene, "nx": a.size, "ny": a.size, "spp": a.spp, "values": int(same.size), "values_different": int((~same).sum()),
+           "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": a.size * a.size * a.spp / cpu_s / 1e6,
+           "gpu_kernel_ms": sc.stats().kernel_ms, "frame_mean": float(gpu.mean())}
+    print(json.dumps(res), flush=True)
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+    return 0 if same.all() else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
