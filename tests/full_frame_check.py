@@ -3,7 +3,7 @@
 every pixel compared bit for bit.  Two minutes of host time on sixteen threads, so it is a script and
 not part of the collected tests:
 
-    python tests/full_frame_check.py [--scene cornell] [--size 1024] [--spp 4096] [--out result.json]
+    python tests/full_frame_check.py [--scene cornell] [--size 1024] [--ny N] [--spp 4096] [--lbvh] [--out result.json]
 
 The oracle renders the frame in tile shards (progress line after each); the GPU renders it in one launch."""
 import argparse
@@ -23,7 +23,9 @@ from tests import _oracle                          # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="cornell")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1024, help="frame width (and height unless --ny is given)")
+    ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--lbvh", action="store_true", help="the GPU walks the library's tree; the oracle always walks the list")
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--shards", type=int, default=32)
     ap.add_argument("--threads", type=int, default=16)
@@ -31,21 +33,24 @@ def main():
     a = ap.parse_args()
     oracle = _oracle.load()
     pt.set_device(0)
-    d = pt.builtin_scene(a.scene, 1.0)
+    nx, ny = a.size, (a.ny or a.size)
+    d = pt.builtin_scene(a.scene, nx / ny)
+    if a.lbvh:
+        d.c.accel = pt.abi.ACCEL_LBVH
     sc = pt.Scene(d)
     t0 = time.perf_counter()
-    gpu = sc.render(a.size, a.size, a.spp)
+    gpu = sc.render(nx, ny, a.spp)
     gpu_s = time.perf_counter() - t0
     print("gpu frame in %.2f s (kernel %.1f ms)" % (gpu_s, sc.stats().kernel_ms), flush=True)
     cpu = np.zeros_like(gpu)
     t0 = time.perf_counter()
     for k in range(a.shards):
-        cpu += oracle.render(d, a.size, a.size, a.spp, shard_index=k, shard_count=a.shards, threads=a.threads)
+        cpu += oracle.render(d, nx, ny, a.spp, shard_index=k, shard_count=a.shards, threads=a.threads)
         print("oracle shard %d/%d, %.0f s" % (k + 1, a.shards, time.perf_counter() - t0), flush=True)
     cpu_s = time.perf_counter() - t0
     same = gpu.view(np.uint32) == cpu.view(np.uint32)
-    res = {"scene": a.scene, "nx": a.size, "ny": a.size, "spp": a.spp, "values": int(same.size), "values_different": int((~same).sum()),
-           "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": a.size * a.size * a.spp / cpu_s / 1e6,
+    res = {"scene": a.scene, "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "values": int(same.size), "values_different": int((~same).sum()),
+           "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": nx * ny * a.spp / cpu_s / 1e6,
            "gpu_kernel_ms": sc.stats().kernel_ms, "frame_mean": float(gpu.mean())}
     print(json.dumps(res), flush=True)
     if a.out:
