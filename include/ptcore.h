@@ -85,7 +85,10 @@ enum PtAccel {
                               /* its first medium or further BVH -- the BVH's leaves become leaves   */
                               /* of the tree, with the reference tree's own answer kept where its   */
                               /* node boxes turn a ray away -- and is walked in order from there.    */
-                              /* Lists the tree cannot stand for fall back to LIST.                  */
+                              /* Lists the tree cannot stand for fall back to LIST.  Rays for which  */
+                              /* the reference's rectangle, box and triangle tests accept a NaN t    */
+                              /* (src/ptRectangle.cu:15: a ray lying in a rectangle's plane, a       */
+                              /* non-finite ray) are answered the in-order way, never by the tree.   */
 };
 
 /* Which scheduler runs the radiance pipeline stages. */
