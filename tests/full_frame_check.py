@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--size", type=int, default=1024, help="frame width (and height unless --ny is given)")
     ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--wavefront", action="store_true", help="the staged scheduler instead of the fused one")
     ap.add_argument("--lbvh", action="store_true", help="the GPU walks the library's tree; the oracle always walks the list")
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--shards", type=int, default=32)
@@ -39,7 +40,8 @@ def main():
         d.c.accel = pt.abi.ACCEL_LBVH
     sc = pt.Scene(d)
     t0 = time.perf_counter()
-    gpu = sc.render(nx, ny, a.spp)
+    kw = {"pipeline": pt.abi.PIPELINE_WAVEFRONT} if a.wavefront else {}
+    gpu = sc.render(nx, ny, a.spp, **kw)
     gpu_s = time.perf_counter() - t0
     print("gpu frame in %.2f s (kernel %.1f ms)" % (gpu_s, sc.stats().kernel_ms), flush=True)
     cpu = np.zeros_like(gpu)
@@ -49,7 +51,7 @@ def main():
         print("oracle shard %d/%d, %.0f s" % (k + 1, a.shards, time.perf_counter() - t0), flush=True)
     cpu_s = time.perf_counter() - t0
     same = gpu.view(np.uint32) == cpu.view(np.uint32)
-    res = {"scene": a.scene, "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "values": int(same.size), "values_different": int((~same).sum()),
+    res = {"scene": a.scene, "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "values": int(same.size), "values_different": int((~same).sum()),
            "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": nx * ny * a.spp / cpu_s / 1e6,
            "gpu_kernel_ms": sc.stats().kernel_ms, "frame_mean": float(gpu.mean())}
     print(json.dumps(res), flush=True)
