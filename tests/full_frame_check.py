@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--size", type=int, default=1024, help="frame width (and height unless --ny is given)")
     ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--trimesh", type=int, default=0, help="the height field of 2*N*N triangles in the Cornell room instead of --scene")
     ap.add_argument("--wavefront", action="store_true", help="the staged scheduler instead of the fused one")
     ap.add_argument("--lbvh", action="store_true", help="the GPU walks the library's tree; the oracle always walks the list")
     ap.add_argument("--spp", type=int, default=4096)
@@ -35,7 +36,7 @@ def main():
     oracle = _oracle.load()
     pt.set_device(0)
     nx, ny = a.size, (a.ny or a.size)
-    d = pt.builtin_scene(a.scene, nx / ny)
+    d = pt.trimesh_scene(a.trimesh, nx / ny) if a.trimesh else pt.builtin_scene(a.scene, nx / ny)
     if a.lbvh:
         d.c.accel = pt.abi.ACCEL_LBVH
     sc = pt.Scene(d)
@@ -51,7 +52,7 @@ def main():
         print("oracle shard %d/%d, %.0f s" % (k + 1, a.shards, time.perf_counter() - t0), flush=True)
     cpu_s = time.perf_counter() - t0
     same = gpu.view(np.uint32) == cpu.view(np.uint32)
-    res = {"scene": a.scene, "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "values": int(same.size), "values_different": int((~same).sum()),
+    res = {"scene": ("trimesh %d" % a.trimesh) if a.trimesh else a.scene, "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "values": int(same.size), "values_different": int((~same).sum()),
            "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": nx * ny * a.spp / cpu_s / 1e6,
            "gpu_kernel_ms": sc.stats().kernel_ms, "frame_mean": float(gpu.mean())}
     print(json.dumps(res), flush=True)
