@@ -787,10 +787,16 @@ __device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, flo
 {
     if (w.cur >= 0) {
         const LbvhNode* n = &sv.lbvh[w.cur];
+        // With triangles in the tree neither end of [tmin, best] bounds the distance: the reference
+        // compares the un-normalised dot(edge2, qvec) = distance * det (src/ptTriangle.cu:65-66), so a
+        // hit a hair in front of the origin (distance << tmin) passes tmin when det > 1 -- a ray
+        // leaving a triangle can hit that same triangle again, and it has left the leaf's box before
+        // tmin.  det > 0 there, so the distance is at least positive.
         const float lim = sv.lbvh_cull != 0 ? w.best : tmax;
+        const float from = sv.lbvh_cull != 0 ? tmin : 0.0f;
         float tl, tr;
-        bool hl = slab(n->lmin, n->lmax, r.o, w.inv, tmin, lim, tl);
-        bool hr = slab(n->rmin, n->rmax, r.o, w.inv, tmin, lim, tr);
+        bool hl = slab(n->lmin, n->lmax, r.o, w.inv, from, lim, tl);
+        bool hr = slab(n->rmin, n->rmax, r.o, w.inv, from, lim, tr);
         int cl = n->left, cr = n->right;
         if (hl && hr) {
             if (tr < tl) { int tmp = cl; cl = cr; cr = tmp; }
@@ -884,8 +890,9 @@ __device__ __attribute__((noinline)) InPlaneHit lbvh_in_plane_t(const SceneView*
         if (cur >= 0) {
             const LbvhNode* nd = &sv.lbvh[cur];
             float tl, tr;
-            const bool hl = slab(nd->lmin, nd->lmax, r.o, inv, tmin, INFINITY, tl);
-            const bool hr = slab(nd->rmin, nd->rmax, r.o, inv, tmin, INFINITY, tr);
+            const float from = sv.lbvh_cull != 0 ? tmin : 0.0f;    // see lbvh_step
+            const bool hl = slab(nd->lmin, nd->lmax, r.o, inv, from, INFINITY, tl);
+            const bool hr = slab(nd->rmin, nd->rmax, r.o, inv, from, INFINITY, tr);
             if (hl && hr) {
                 if (sp == LBVH_STACK) return out;
                 pending[sp++] = nd->right;

@@ -766,6 +766,31 @@ def test_render_with_every_primary_ray_in_the_lamps_plane(oracle, schedule):
     assert ((rays["d"][:, 1] == 0) & (rays["o"][:, 1] == 554.0)).sum() >= 200
 
 
+def test_a_ray_leaving_a_triangle_hits_it_again_through_the_tree(oracle):
+    """The reference compares the un-normalised dot(edge2, qvec) = distance * det with tmin
+    (src/ptTriangle.cu:65-66), so a ray that starts on a triangle can hit it again at a distance far
+    below tmin when det > 1 -- by which time it has already left the leaf's box.  Found by the
+    full-frame comparison of a 20 000-triangle field (one pixel); the tree's box tests start at
+    distance 0 when it holds triangles."""
+    d = pt.trimesh_scene(100, 480 / 270)                       # the field's description asks for the library's tree
+    assert d.c.accel == abi.ACCEL_LBVH
+    rays = np.zeros(64, RAY_DTYPE)
+    rays["o"][:] = np.array([128.23375, 202.80565, 427.79727], np.float32)
+    rays["d"][:] = np.array([114.62236, 351.19434, -154.21857], np.float32)
+    rays["time"][:] = np.float32(0.19645828)
+    ids_o, t_o = oracle.trace_closest(d, rays)
+    assert ids_o[0] == 16640 and t_o[0] < 0.002                 # the triangle the ray starts on
+    ids_g, t_g = pt.Scene(d).trace_closest(rays)
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+    # and rays leaving the field in general: origins on triangles, directions upwards
+    rec = oracle.record_rays(d, 96, 54, 4, 60000)
+    ids_o, t_o = oracle.trace_closest(d, rec)
+    ids_g, t_g = pt.Scene(d).trace_closest(rec)
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+
+
 def _random_world(rng, base):
     """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
     rectangles (some flipped, some wrapped boxes), triangles, an optional reference BVH at the head of the
