@@ -28,6 +28,7 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (fn == 7) { out[i] = ptm::atan2f_glibc(x[2 * i], x[2 * i + 1]); return; }
     const float v = x[i];
     float r;
     switch (fn) {
@@ -35,6 +36,7 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
     case 1: r = ptm::cosf_glibc(v); break;
     case 2: r = ptm::logf_glibc(v); break;
     case 3: r = ptm::pow5f_glibc(v); break;
+    case 6: r = ptm::asinf_glibc(v); break;
     default: { float sn, cs; ptm::sincosf_glibc(v, &sn, &cs); r = fn == 4 ? sn : cs; } break;
     }
     out[i] = r;
@@ -129,7 +131,7 @@ extern "C" void pt_comm_destroy(PtComm* c)
 
 extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device)
 {
-    if (fn < 0 || fn > 5 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
+    if (fn < 0 || fn > 7 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
     if (n == 0) return PT_OK;
     if (!on_device) {
         for (size_t i = 0; i < n; i++) {
@@ -138,6 +140,8 @@ extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on
             case 1: out[i] = ptm::cosf_glibc(x[i]); break;
             case 2: out[i] = ptm::logf_glibc(x[i]); break;
             case 3: out[i] = ptm::pow5f_glibc(x[i]); break;
+            case 6: out[i] = ptm::asinf_glibc(x[i]); break;
+            case 7: out[i] = ptm::atan2f_glibc(x[2 * i], x[2 * i + 1]); break;
             default: { float sn, cs; ptm::sincosf_glibc(x[i], &sn, &cs); out[i] = fn == 4 ? sn : cs; } break;
             }
         }
@@ -145,10 +149,11 @@ extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on
     }
     float *dx = nullptr, *dy = nullptr;
     hipError_t e;
-    if ((e = hipMalloc((void**)&dx, n * 4)) != hipSuccess) return hip_err(e, "hipMalloc");
+    const size_t n_in = fn == 7 ? 2 * n : n;
+    if ((e = hipMalloc((void**)&dx, n_in * 4)) != hipSuccess) return hip_err(e, "hipMalloc");
     if ((e = hipMalloc((void**)&dy, n * 4)) != hipSuccess) { (void)hipFree(dx); return hip_err(e, "hipMalloc"); }
     int rc = PT_OK;
-    if ((e = hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice)) != hipSuccess) rc = hip_err(e, "hipMemcpy");
+    if ((e = hipMemcpy(dx, x, n_in * 4, hipMemcpyHostToDevice)) != hipSuccess) rc = hip_err(e, "hipMemcpy");
     if (rc == PT_OK) {
         hipLaunchKernelGGL(k_libm_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, fn, dx, n, dy);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) rc = hip_err(e, "libm kernel");

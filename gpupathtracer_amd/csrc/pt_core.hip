@@ -262,6 +262,12 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
                     if (any) { h.t = got.t; h.id = got.id; h.face = got.face; }
                 }
             }
+            if (F & F_IMAGE) {
+                // a plain sphere whose texture reads uv shows the uv of the hit the in-order walk accepted
+                // before it, which the tree does not know: that ray is searched again in list order
+                if (sv.reads_uv && any && hit_reads_stale_uv<F>(sv, h.id))
+                    any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+            }
             bool ended;
             if (any) {
                 ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);

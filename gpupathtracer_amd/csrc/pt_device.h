@@ -10,8 +10,8 @@
 // one rounding per operation (build with -ffp-contract=off; HIP's default correctly-rounded
 // fp32 divide and sqrt).  Where the reference's C++ leaves an order unspecified the order
 // g++ picks is used (z before x in XZRectangle::random).  sin, cos, log and pow(.,5) are the
-// host libm's results bit for bit (pt_libm.h); atan2f/asinf (MovingSphere uv, read only by image
-// textures) are the device library's.
+// host libm's results bit for bit (pt_libm.h), and so are atan2f/asinf (MovingSphere uv, read only
+// by image textures).
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H
 
@@ -1048,6 +1048,20 @@ __device__ __forceinline__ bool world_hit_sig(const SceneView& sv, const Ray& r,
 template <class W> struct is_any_world { static constexpr bool value = false; };
 template <> struct is_any_world<AnyWorld> { static constexpr bool value = true; };
 
+// True when the winner `id` writes no uv of its own (a plain sphere, a medium) and its material's
+// texture can read uv: then the uv of an earlier accepted hit shows through (see Hit).
+template <uint32_t F>
+__device__ __forceinline__ bool hit_reads_stale_uv(const SceneView& sv, int id)
+{
+    int m;
+    if ((F & F_MEDIUM) && id >= PT_ID_MEDIUM_BASE) m = sv.media[id - PT_ID_MEDIUM_BASE].material;
+    else if (id >= 0 && !writes_uv(sv.shapes[id].type)) m = sv.shapes[id].material;
+    else return false;
+    const int tex = m >= 0 ? sv.materials[m].texture : -1;
+    const int kind = tex >= 0 ? sv.textures[tex].type : PT_TEX_CONSTANT;
+    return kind == PT_TEX_IMAGE || kind == PT_TEX_CHECKER;
+}
+
 // world->hit(ray, tmin, tmax) (src/ptHitableList.cu:12-27).
 // lbvh_stack: this lane's column of the LDS traversal stack (stride 64 ints), or nullptr.
 template <uint32_t F, class W = AnyWorld>
@@ -1140,12 +1154,7 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
         if (!((F & F_LBVH) && (F & F_IMAGE))) break;
         // the one case the tree could not settle: the search ends on a plain sphere that may read a uv the tree did not see
         bool again = false;
-        if (uv_unknown && any && h.id < PT_ID_MEDIUM_BASE && !writes_uv(sv.shapes[h.id].type)) {
-            const int m = sv.shapes[h.id].material;
-            const int tex = m >= 0 ? sv.materials[m].texture : -1;
-            const int kind = tex >= 0 ? sv.textures[tex].type : PT_TEX_CONSTANT;
-            again = kind == PT_TEX_IMAGE || kind == PT_TEX_CHECKER;
-        }
+        if (uv_unknown && any) again = hit_reads_stale_uv<F>(sv, h.id);
         if (!again) break;
         uv_unknown = false; g = g_before; first = 0;
         any = false; closest = tmax;
@@ -1159,8 +1168,8 @@ struct Surface { V3 p, n; float u, v; int32_t mat; };
 
 __device__ __forceinline__ void get_uv(V3 p, float& u, float& v)     // include/ptSphere.h:22-28
 {
-    float phi = atan2f(p.z, p.x);
-    float theta = asinf(p.y);
+    float phi = ptm::atan2f_glibc(p.z, p.x);
+    float theta = ptm::asinf_glibc(p.y);
     u = 1 - (phi + PI_F) / (2 * PI_F);
     v = (theta + PI_F / 2) / PI_F;
 }
@@ -1214,15 +1223,27 @@ __device__ __forceinline__ void leaf_uv(const SceneView& sv, const PtShape* s, c
     }
 }
 
+// uv left in the list's record by the last uv-writing hit the walk accepted before the winner
+// (see Hit): what a plain sphere or a medium, which write no uv of their own, hand to the shader.
+template <uint32_t F>
+__device__ __forceinline__ void stale_uv(const SceneView& sv, const Ray& ray, const Hit& h, float& u, float& v)
+{
+    const PtShape* us = &sv.shapes[h.uv_id];
+    Ray ur = ray;
+    if (F & F_XFORM) { if (us->xform_count > 0) ur = to_local(sv, us->xform_first, us->xform_count, ray); }
+    leaf_uv<F>(sv, us, ur, h.uv_t, h.uv_face, u, v);
+}
+
 template <uint32_t F>
 __device__ __forceinline__ Surface complete_hit(const SceneView& sv, const Ray& ray, const Hit& h)
 {
     Surface sf;
     sf.u = 0.0f; sf.v = 0.0f;
-    if ((F & F_MEDIUM) && h.id >= PT_ID_MEDIUM_BASE) {            // include/ptMedium.h:46-49
+    if ((F & F_MEDIUM) && h.id >= PT_ID_MEDIUM_BASE) {            // include/ptMedium.h:46-49: t, p, normal, material; uv stays
         sf.p = at(ray, h.t);
         sf.n = mk(1, 0, 0);
         sf.mat = sv.media[h.id - PT_ID_MEDIUM_BASE].material;
+        if (F & F_IMAGE) { if (h.uv_id >= 0) stale_uv<F>(sv, ray, h, sf.u, sf.v); }
         return sf;
     }
     const PtShape* s = &sv.shapes[h.id];
@@ -1264,12 +1285,7 @@ __device__ __forceinline__ Surface complete_hit(const SceneView& sv, const Ray& 
     if (F & F_IMAGE) {
         // uv is read by image textures only
         if (writes_uv(type)) leaf_uv<F>(sv, s, r, h.t, h.face, sf.u, sf.v);
-        else if (h.uv_id >= 0) {
-            const PtShape* us = &sv.shapes[h.uv_id];
-            Ray ur = ray;
-            if (F & F_XFORM) { if (us->xform_count > 0) ur = to_local(sv, us->xform_first, us->xform_count, ray); }
-            leaf_uv<F>(sv, us, ur, h.uv_t, h.uv_face, sf.u, sf.v);
-        }
+        else if (h.uv_id >= 0) stale_uv<F>(sv, ray, h, sf.u, sf.v);
     }
     if (F & F_XFORM) { if (nxf > 0) to_world(sv, s->xform_first, nxf, sf.p, sf.n); }
     if (s->flags & PT_FLIP_NORMAL) sf.n = -sf.n;                   // include/ptRectangle.h:148-156
@@ -1326,6 +1342,13 @@ __device__ inline float turbulence7(V3 p)                           // src/ptNoi
 }
 
 // ---- textures (include/ptTexture.h) --------------------------------------------------------------------
+// float -> int as the reference's x86-64 host build converts (cvttss2si): NaN and every value
+// outside [-2^31, 2^31) give INT_MIN, where the GPU's conversion would give 0 or saturate.  A moving
+// sphere's uv is NaN whenever |p.y| > 1 (asinf of the un-normalised point, include/ptSphere.h:22-28).
+__device__ __forceinline__ int f2i_host(float x)
+{
+    return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000;
+}
 template <uint32_t F>
 __device__ __forceinline__ V3 texture_value(const SceneView& sv, int tex, float u, float v, V3 p)
 {
@@ -1343,8 +1366,8 @@ __device__ __forceinline__ V3 texture_value(const SceneView& sv, int tex, float 
     }
     if ((F & F_IMAGE) && t.type == PT_TEX_IMAGE) {                  // :187-199
         int nx = t.nx, ny = t.ny;
-        int i = (int)(u * nx);
-        int j = (int)((1 - v) * ny - 0.001f);
+        int i = f2i_host(u * nx);
+        int j = f2i_host((1 - v) * ny - 0.001f);
         i = max(0, i); j = max(0, j);
         i = min(i, nx - 1); j = min(j, ny - 1);
         const uint8_t* d = sv.texels + t.texel_offset + 3 * i + 3 * nx * j;

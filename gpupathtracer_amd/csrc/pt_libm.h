@@ -10,10 +10,24 @@
 // equal the host's.  logf and powf follow the same library's table-driven log / log2 / exp2 kernels.
 // Checked against this image's libm: sinf and cosf on every finite float of both signs, logf on every
 // positive finite float, powf(x, 5) on every normal x in (0, 2] -- no mismatch for any of them.
+// asinf and atan2f (MovingSphere's uv, include/ptSphere.h:22-28) follow the same library's
+// single-precision fdlibm code, which its x86-64 build compiles without fused multiply-adds:
+// asinf equal on all 2^32 floats, atanf on all 2^32, atan2f on 2^31 pseudo-random pairs (an eighth
+// of them with exponents within 4 of each other) and a grid of special values.
+//
+// Provenance of the algorithms and constants restated here: sinf/cosf/sincosf/logf/powf are glibc
+// 2.35's sysdeps/ieee754/flt-32/{s_sincosf.h,e_logf.c,e_powf.c,e_exp2f_data.c}, contributed by Arm
+// (Optimized Routines, Copyright (c) Arm Limited, MIT / LGPL-2.1-or-later as distributed in glibc);
+// asinf/atanf/atan2f are glibc 2.35's e_asinf.c, s_atanf.c, e_atan2f.c, derived from FreeBSD /
+// fdlibm: "Copyright (C) 1993 by Sun Microsystems, Inc.  All rights reserved.  Developed at SunPro,
+// a Sun Microsystems, Inc. business.  Permission to use, copy, modify, and distribute this software
+// is freely granted, provided that this notice is preserved."  The code below is a re-expression
+// for host and device, not a copy of those files.
 #ifndef PT_LIBM_H
 #define PT_LIBM_H
 
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 
 #if defined(__HIPCC__)
@@ -329,6 +343,97 @@ PT_HD float pow5f_glibc(float x)
     yy = __builtin_fma(zz, rr2, yy);
     yy = yy * s;
     return (float)yy;
+}
+
+// ---- asinf, atanf, atan2f: plain single-precision evaluation, one rounding per operation -----------
+PT_HD float asinf_glibc(float x)
+{
+    const float pio2_hi = 1.57079637050628662109375f, pio2_lo = -4.37113900018624283e-8f, pio4_hi = 0.785398185253143310546875f;
+    const float p0 = 1.666675248e-1f, p1 = 7.495297643e-2f, p2 = 4.547037598e-2f, p3 = 2.417951451e-2f, p4 = 4.216630880e-2f;
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return x * pio2_hi + x * pio2_lo;               // asin(+-1) = +-pi/2
+    if (ix > 0x3f800000) return (x - x) / (x - x);                        // |x| > 1 or NaN
+    if (ix < 0x3f000000) {                                                // |x| < 0.5
+        if (ix < 0x32000000) return x;                                    // |x| < 2^-27
+        const float t = x * x;
+        const float w = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+        return x + x * w;
+    }
+    const float w = 1.0f - fabsf(x);
+    float t = w * 0.5f;
+    float p = t * (p0 + t * (p1 + t * (p2 + t * (p3 + t * p4))));
+    const float s = sqrtf(t);
+    if (ix >= 0x3F79999A) {                                               // |x| > 0.975
+        t = pio2_hi - (2.0f * (s + s * p) - pio2_lo);
+    } else {
+        const float sh = u2f(f2u(s) & 0xfffff000u);                       // s with its low 12 bits cleared
+        const float c = (t - sh * sh) / (s + sh);
+        const float r = p;
+        p = 2.0f * s * r - (pio2_lo - 2.0f * c);
+        const float q = pio4_hi - 2.0f * sh;
+        t = pio4_hi - (p - q);
+    }
+    return hx > 0 ? t : -t;
+}
+
+PT_HD float atanf_glibc(float x)
+{
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    float hi = 0.0f, lo = 0.0f;                                           // atan of the interval's pivot, in two parts
+    bool reduced = true;
+    if (ix >= 0x4c000000) {                                               // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        const float h3 = u2f(0x3fc90fda), l3 = u2f(0x33a22168);
+        return hx > 0 ? h3 + l3 : -h3 - l3;
+    }
+    if (ix < 0x3ee00000) {                                                // |x| < 7/16
+        if (ix < 0x31000000) return x;                                    // |x| < 2^-29
+        reduced = false;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {                                            // |x| < 19/16
+            if (ix < 0x3f300000) { hi = u2f(0x3eed6338); lo = u2f(0x31ac3769); x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { hi = u2f(0x3f490fda); lo = u2f(0x33222168); x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { hi = u2f(0x3f7b985e); lo = u2f(0x33140fb4); x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { hi = u2f(0x3fc90fda); lo = u2f(0x33a22168); x = -1.0f / x; }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (u2f(0x3eaaaaab) + w * (u2f(0x3e124925) + w * (u2f(0x3dba2e6e) + w * (u2f(0x3d886b35) + w * (u2f(0x3d4bda59) + w * u2f(0x3c8569d7))))));
+    const float s2 = w * (u2f(0xbe4ccccd) + w * (u2f(0xbde38e38) + w * (u2f(0xbd9d8795) + w * (u2f(0xbd6ef16b) + w * u2f(0xbd15a221)))));
+    if (!reduced) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+PT_HD float atan2f_glibc(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = u2f(0x3f490fdb), pi_o_2 = u2f(0x3fc90fdb), pi = u2f(0x40490fdb), pi_lo = u2f(0xb3bbbd2e);
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;                 // NaN
+    if (hx == 0x3f800000) return atanf_glibc(y);                          // x = 1
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                    // 2 * sign(x) + sign(y)
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                                // |y / x| > 2^60
+    else if (hx < 0 && k < -60) z = 0.0f;                                 // |y| / x < -2^60
+    else z = atanf_glibc(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return u2f(f2u(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
 }
 
 }  // namespace ptm

@@ -385,7 +385,8 @@ void pt_comm_destroy(PtComm* comm);
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* Evaluates one of the library's libm replacements on n floats: fn 0 sin, 1 cos, 2 log, 3 x^5
  * (the reference's Sin/Cos/Log/Pow wrappers, include/ptMath.h:34-45); fn 4 and 5 are the sine and
- * the cosine from the combined evaluation the direction samplers use, equal to fn 0 and 1.  on_device != 0 runs the
+ * the cosine from the combined evaluation the direction samplers use, equal to fn 0 and 1; fn 6 asin; fn 7 atan2,
+ * where x holds n (y, x) pairs, 2 * n floats (MovingSphere's get_uv, include/ptSphere.h:22-28).  on_device != 0 runs the
  * device code on the current HIP device, otherwise the same source compiled for the host. */
 int  pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device);
 

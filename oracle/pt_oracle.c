@@ -1040,6 +1040,8 @@ int oracle_work_counters(uint64_t* out, int n)
 
 int oracle_trace_closest(const PtSceneDesc* sc, const PtRay* rays, size_t n, int32_t* prim_id, float* t)
 {
+    /* rays are independent (each seeds its own generator): threads only shorten the wait on large worlds */
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t i = 0; i < n; i++) {
         ray_t r;
         r.o = V(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
@@ -1058,6 +1060,7 @@ int oracle_trace_closest(const PtSceneDesc* sc, const PtRay* rays, size_t n, int
 /* Full hit record for unit checks: out = t, p xyz, n xyz, u, v (9 floats per ray). */
 int oracle_trace_records(const PtSceneDesc* sc, const PtRay* rays, size_t n, int32_t* prim_id, float* out9)
 {
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t i = 0; i < n; i++) {
         ray_t r;
         r.o = V(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
@@ -1126,6 +1129,24 @@ size_t oracle_record_rays_ns(const PtSceneDesc* sc, int nx, int ny, int ns, int 
         }
     }
     return n;
+}
+/* The first camera ray of each listed pixel (pixel = render_kernel's index i, src/ptMain.cu:178), as
+ * render_pixel generates it (src/ptMain.cu:158-160); no world is searched, so this is cheap on
+ * worlds of any size. */
+void oracle_camera_rays(const PtSceneDesc* sc, int nx, int ny, const uint32_t* pixels, size_t n, PtRay* out)
+{
+    for (size_t k = 0; k < n; k++) {
+        const unsigned i = pixels[k];
+        const int ytop = (int)(i / (unsigned)nx), x = (int)(i % (unsigned)nx), y = ny - 1 - ytop;
+        pcg_t rng;
+        pcg_seed(&rng, i);
+        float u = (x + pcg_rand(&rng)) / (float)nx;
+        float v = (y + pcg_rand(&rng)) / (float)ny;
+        ray_t r = camera_get_ray(sc, u, v, &rng);
+        out[k].o[0] = r.o.x; out[k].o[1] = r.o.y; out[k].o[2] = r.o.z;
+        out[k].d[0] = r.d.x; out[k].d[1] = r.d.y; out[k].d[2] = r.d.z;
+        out[k].time = r.time; out[k].seed = (uint32_t)k;
+    }
 }
 size_t oracle_record_rays(const PtSceneDesc* sc, int nx, int ny, int max_depth, PtRay* out, size_t capacity)
 {
@@ -1208,14 +1229,18 @@ uint64_t oracle_fnv1a(const void* data, size_t n_bytes)
 }
 
 /* The host libm the reference's Sin/Cos/Log/Pow wrappers resolve to (include/ptMath.h:34-45):
- * fn 0 sinf, 1 cosf, 2 logf, 3 powf(x, 5). */
+ * fn 0 sinf, 1 cosf, 2 logf, 3 powf(x, 5); and get_uv's calls (include/ptSphere.h:22-28):
+ * fn 6 asinf, fn 7 atan2f on n (y, x) pairs (x then holds 2 * n floats). */
 void oracle_libm(int fn, const float* x, size_t n, float* out)
 {
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         switch (fn) {
         case 0: out[i] = sinf(x[i]); break;
         case 1: out[i] = cosf(x[i]); break;
         case 2: out[i] = logf(x[i]); break;
+        case 6: out[i] = asinf(x[i]); break;
+        case 7: out[i] = atan2f(x[2 * i], x[2 * i + 1]); break;
         default: out[i] = powf(x[i], 5); break;
         }
     }

@@ -58,3 +58,24 @@ class OwnedDesc:
     @property
     def c(self):
         return self.desc
+
+
+def look_at_camera(frm, to, vup, vfov, aspect, aperture, focus, t0=0.0, t1=1.0):
+    """The 24 camera floats in the layout of include/ptCamera.h:43-49, derived the way the reference's
+    constructor derives them (src/ptCamera.cu:27-45) but in numpy float32: an input for both sides of
+    a parity test, not a claim about the constructor's bits."""
+    import numpy as np
+    f = np.float32
+    frm, to, vup = (np.asarray(v, f) for v in (frm, to, vup))
+    half_h = f(np.tan(f(vfov) * f(np.pi) / f(180) / f(2)))
+    half_w = f(aspect) * half_h
+    w = frm - to
+    w = w / f(np.linalg.norm(w))
+    u = np.cross(vup, w).astype(f)
+    u = u / f(np.linalg.norm(u))
+    v = np.cross(w, u).astype(f)
+    fd = f(focus)
+    llc = frm - half_w * fd * u - half_h * fd * v - fd * w
+    cam = list(frm) + list(llc) + list(f(2) * half_w * fd * u) + list(f(2) * half_h * fd * v) + list(u) + list(v) + list(w)
+    cam += [t0, t1, aperture / 2.0]
+    return [float(f(x)) for x in cam]

@@ -23,6 +23,7 @@ class Oracle:
         lib.oracle_record_rays.restype = C.c_size_t
         lib.oracle_record_rays_ns.argtypes = [P(A.PtSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.oracle_record_rays_ns.restype = C.c_size_t
+        lib.oracle_camera_rays.argtypes = [P(A.PtSceneDesc), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.oracle_pcg_stream.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
         lib.oracle_simple_rng_stream.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_void_p]
         lib.oracle_noise.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -69,6 +70,14 @@ class Oracle:
         n = self.lib.oracle_record_rays_ns(desc.ptr, nx, ny, ns, max_depth, only_pixel, rays.ctypes.data, capacity)
         return rays[:n].copy()
 
+    def camera_rays(self, desc, nx, ny, pixels):
+        """First camera ray of each pixel index in `pixels` (no world search)."""
+        from gpupathtracer_amd.api import RAY_DTYPE
+        px = np.ascontiguousarray(pixels, np.uint32)
+        rays = np.zeros(px.size, RAY_DTYPE)
+        self.lib.oracle_camera_rays(desc.ptr, nx, ny, px.ctypes.data, px.size, rays.ctypes.data)
+        return rays
+
     def median_filter(self, image, size=3):
         img = np.ascontiguousarray(image, np.float32)
         out = np.empty_like(img)
@@ -109,10 +118,12 @@ class Oracle:
         return out
 
     def libm(self, fn, x):
+        """fn 0 sin, 1 cos, 2 log, 3 x**5, 6 asin, 7 atan2 of (y, x) pairs (shape (n, 2))."""
         x = np.ascontiguousarray(x, np.float32)
-        out = np.empty_like(x)
-        self.lib.oracle_libm(fn, x.ctypes.data, x.size, out.ctypes.data)
-        return out
+        n = x.size // 2 if fn == 7 else x.size
+        out = np.empty(n, np.float32)
+        self.lib.oracle_libm(fn, x.ctypes.data, n, out.ctypes.data)
+        return out.reshape(x.shape[:-1]) if fn == 7 else out.reshape(x.shape)
 
     def fnv1a(self, arr):
         arr = np.ascontiguousarray(arr)

@@ -82,6 +82,15 @@ def test_libm_host_build_matches_glibc(oracle):
         b = oracle.libm(fn - 4 if fn >= 4 else fn, arg)
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (fn, arg[~same][:5])
+    # asin and atan2 of MovingSphere's uv (include/ptSphere.h:22-28)
+    xs = np.concatenate([rng.uniform(-1.2, 1.2, 400_000), x[:400_000] / 130]).astype(np.float32)
+    a, b = pt.libm_eval(6, xs, on_device=False), oracle.libm(6, xs)
+    assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1e-38, 0.5, 2.0, 1e30, 1e-30], np.float32)
+    yx = np.concatenate([rng.normal(size=(400_000, 2)) * 10.0 ** rng.uniform(-30, 30, (400_000, 1)), rng.normal(size=(400_000, 2)),
+                         np.stack(np.meshgrid(special, special), -1).reshape(-1, 2)]).astype(np.float32)
+    a, b = pt.libm_eval(7, yx, on_device=False), oracle.libm(7, yx)
+    assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
 
 
 def test_corrupted_descriptions_are_refused_not_executed():

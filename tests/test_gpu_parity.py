@@ -1,9 +1,8 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
 
 Bar: bit-exact.  Closest hits must agree in primitive id and in the bits of t; images must agree in
-every bit of every channel (the device evaluates sin/cos/log/pow exactly as the host libm does, so
-there is no tolerance to state).  The one exception is named where it applies: uv of moving
-spheres (atan2f/asinf come from the device library), which only image textures read.
+every bit of every channel (the device evaluates sin/cos/log/pow/asin/atan2 exactly as the host libm
+does, so there is no tolerance to state).
 """
 import json
 import os
@@ -189,6 +188,16 @@ def test_device_libm_matches_glibc(oracle):
         b = oracle.libm(fn - 4 if fn >= 4 else fn, arg)
         same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (fn, arg[~same][:5], a[~same][:5], b[~same][:5])
+    # asin and atan2 of MovingSphere's uv (include/ptSphere.h:22-28)
+    xs = np.concatenate([rng.uniform(-1.2, 1.2, 1_000_000), x[:1_000_000] / 130]).astype(np.float32)
+    a, b = pt.libm_eval(6, xs, on_device=True), oracle.libm(6, xs)
+    assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1e-38, 0.5, 2.0, 1e30, 1e-30], np.float32)
+    yx = np.concatenate([rng.normal(size=(1_000_000, 2)) * 10.0 ** rng.uniform(-30, 30, (1_000_000, 1)), rng.normal(size=(1_000_000, 2)),
+                         np.stack(np.meshgrid(special, special), -1).reshape(-1, 2)]).astype(np.float32)
+    a, b = pt.libm_eval(7, yx, on_device=True), oracle.libm(7, yx)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), (yx[~same][:5], a[~same][:5], b[~same][:5])
 
 
 def test_render_into_device_memory_and_single_rank_rccl(oracle):
@@ -791,13 +800,28 @@ def test_a_ray_leaving_a_triangle_hits_it_again_through_the_tree(oracle):
     np.testing.assert_array_equal(bits(t_g), bits(t_o))
 
 
-def _random_world(rng, base):
+def _random_world(rng, base, textured=False):
     """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
     rectangles (some flipped, some wrapped boxes), triangles, an optional reference BVH at the head of the
-    list or later in it (median splits, boxes = unions of the leaves' bounds), optional media."""
+    list or later in it (median splits, boxes = unions of the leaves' bounds), optional media.
+    textured: `base` carries an image texture; checker (of image and noise, and nested), noise and image
+    textures are put on Lambertian, Isotropic and DiffuseLight materials, and a few small moving
+    spheres sit near the origin, where their uv (asinf of the world-space y) is finite."""
     from tests._desc_tools import OwnedDesc
     from gpupathtracer_amd import _abi as A
     g = OwnedDesc(base)
+    if textured:
+        tx, ms = g.lists["textures"], g.lists["materials"]
+        image = next(i for i, t in enumerate(tx) if t.type == abi.TEX_IMAGE)
+        noise = next(i for i, t in enumerate(tx) if t.type == abi.TEX_NOISE)
+        const = next(i for i, t in enumerate(tx) if t.type == abi.TEX_CONSTANT)
+        tx.append(A.PtTexture(type=abi.TEX_CHECKER, odd=image, even=noise, scale=float(rng.uniform(0.05, 0.5)))); chk = len(tx) - 1
+        tx.append(A.PtTexture(type=abi.TEX_CHECKER, odd=chk, even=const, scale=float(rng.uniform(0.5, 3.0)))); chk2 = len(tx) - 1
+        for t in (image, noise, chk, chk2):
+            ms.append(A.PtMaterial(type=abi.MAT_LAMBERTIAN, texture=t))
+        ms.append(A.PtMaterial(type=abi.MAT_ISOTROPIC, texture=image))
+        ms.append(A.PtMaterial(type=abi.MAT_ISOTROPIC, texture=chk2))
+        ms.append(A.PtMaterial(type=abi.MAT_DIFFUSE_LIGHT, texture=chk))
     mats = [i for i, m in enumerate(g.lists["materials"])]
     shapes, xforms, bounds = [], [], []
 
@@ -817,6 +841,13 @@ def _random_world(rng, base):
     import ctypes as C
     n = int(rng.integers(12, 90))
     plain = []                                                 # (shape id, kind class, lo, hi): candidates for a reference BVH
+    if textured:
+        for _ in range(int(rng.integers(1, 4))):
+            c = rng.uniform(-0.4, 0.4, 3).astype(np.float32)
+            c1 = (c + rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+            r = np.float32(rng.uniform(0.2, 0.5))
+            i = add(abi.SHAPE_MOVING_SPHERE, [c[0], c[1], c[2], c1[0], c1[1], c1[2], 0.0, 1.0, r])
+            plain.append((i, 0, np.minimum(c, c1) - r, np.maximum(c, c1) + r))
     for _ in range(n):
         c = rng.uniform(-50, 50, 3).astype(np.float32)
         r = np.float32(rng.uniform(1, 12))
@@ -883,7 +914,8 @@ def _random_world(rng, base):
     spheres = [i for i in rest if shapes[i].type == abi.SHAPE_SPHERE]
     if spheres and rng.random() < 0.6:
         boundary = spheres[0]
-        iso = next(i for i, m in enumerate(g.lists["materials"]) if m.type == abi.MAT_ISOTROPIC)
+        isos = [i for i, m in enumerate(g.lists["materials"]) if m.type == abi.MAT_ISOTROPIC]
+        iso = isos[int(rng.integers(0, len(isos)))] if textured else isos[0]
         media.append(A.PtMedium(boundary=boundary, density=0.02, material=iso))
     entries = [A.PtObject(type=abi.OBJ_SHAPE, index=i) for i in rest]
     if media:
@@ -945,3 +977,34 @@ def test_random_worlds_match_the_oracle(oracle, seed):
         if ref is None:
             ref = oracle.render(g, 48, 24, 4)
         assert_bit_exact(sc.render(48, 24, 4), ref, "random world %d accel %d" % (seed, accel))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16"))))
+def test_random_textured_worlds_through_a_lens_match_the_oracle(oracle, seed):
+    """The random worlds again with image, noise and (nested) checker textures on their Lambertian,
+    Isotropic and DiffuseLight materials -- so the uv of every kind of hit is read, the stale uv of
+    plain spheres and media included -- seen through a thin lens half of the time."""
+    rng = np.random.default_rng(5000 + seed)
+    tex = rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)
+    g = _random_world(rng, pt.builtin_scene("final", 16 / 9, earth_rgb=tex), textured=True)
+    cam = pt.builtin_scene("simple_spheres", 2.0).c.camera
+    g.camera = [float(cam[k]) * (12.0 if k < 3 else 1.0) for k in range(24)]
+    g.camera[23] = 0.0 if seed % 2 == 0 else float(rng.uniform(0.01, 2.0))
+    g.scalars["ambient_type"] = 2                               # sky: paths that leave carry their textures' colours into the frame
+    rays = random_rays(rng, 20000, -70, 70)
+    near = random_rays(rng, 4000, -3, 3)                        # towards the small moving spheres about the origin
+    near["d"] = (-near["o"] + rng.normal(size=(4000, 3)) * 0.3).astype(np.float32)
+    rays = np.concatenate([rays, near])
+    ref = None
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        ids_o, t_o = oracle.trace_closest(g, rays)
+        ids_g, t_g = sc.trace_closest(rays)
+        np.testing.assert_array_equal(ids_g, ids_o)
+        np.testing.assert_array_equal(bits(t_g), bits(t_o))
+        if ref is None:
+            ref = oracle.render(g, 64, 32, 6)
+        assert_bit_exact(sc.render(64, 32, 6), ref, "textured world %d accel %d" % (seed, accel))
+        assert_bit_exact(sc.render(64, 32, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, "textured world %d accel %d staged" % (seed, accel))
