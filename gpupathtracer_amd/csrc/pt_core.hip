@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(Scene
 // (src/ptMain.cu:163-166) applied to the samples that exist.
 template <uint32_t F, class W>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
-                                                     int first, float* __restrict__ out)
+                                                     int first, float* __restrict__ out, int* __restrict__ bad_resume)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     const int lane = threadIdx.x & 63;
@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
     lane_begin_pixel(st, ra, x, ytop, i);
     if (first > 0) {
         const PtAccumPixel a = acc[i];
+        if (a.samples != (uint32_t)first) *bad_resume = 1;    // not the state the earlier passes left: the host reports it
         st.rng.state = ((uint64_t)a.rng_hi << 32) | a.rng_lo;
         st.accum = mk(a.sum[0], a.sum[1], a.sum[2]);
         st.s = first;
@@ -395,10 +396,11 @@ void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float
 #undef PT_LAUNCH
 }
 
-void launch_pass(int variant, const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, hipStream_t st)
+void launch_pass(int variant, const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume,
+                 hipStream_t st)
 {
     const dim3 block(256), grid((ra.n_wave_tiles + 3) / 4);
-#define PT_LAUNCH(F, W) hipLaunchKernelGGL((k_render_pass<F, W>), grid, block, 0, st, sv, ra, acc, first, out)
+#define PT_LAUNCH(F, W) hipLaunchKernelGGL((k_render_pass<F, W>), grid, block, 0, st, sv, ra, acc, first, out, bad_resume)
     PT_FOR_VARIANT(variant, PT_LAUNCH)
 #undef PT_LAUNCH
 }
@@ -829,6 +831,16 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         sc->allocs.push_back(ctr);
         sc->next_slot = static_cast<unsigned*>(ctr);
     }
+    {
+        // a word of pinned host memory the pass kernel can write: "this accumulator is not where first_sample says"
+        void* flag = nullptr;
+        if (!hip_ok(hipHostMalloc(&flag, 64, hipHostMallocMapped), "hipHostMalloc(resume flag)")) { pt_scene_destroy(sc); return PT_ERR_OOM; }
+        sc->bad_resume_host = static_cast<int*>(flag);
+        *sc->bad_resume_host = 0;
+        void* dev = nullptr;
+        if (!hip_ok(hipHostGetDevicePointer(&dev, flag, 0), "hipHostGetDevicePointer")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+        sc->bad_resume_dev = static_cast<int*>(dev);
+    }
     ok = hip_ok(hipEventCreate(&sc->ev_begin), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_k0), "hipEventCreate")
       && hip_ok(hipEventCreate(&sc->ev_k1), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_end), "hipEventCreate");
     if (!ok) { pt_scene_destroy(sc); return PT_ERR_HIP; }
@@ -840,6 +852,7 @@ extern "C" void pt_scene_destroy(PtScene* sc)
 {
     if (!sc) return;
     for (void* p : sc->allocs) (void)hipFree(p);
+    if (sc->bad_resume_host) (void)hipHostFree(sc->bad_resume_host);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);
     if (sc->ev_k1) (void)hipEventDestroy(sc->ev_k1);
@@ -864,7 +877,10 @@ bool make_args(const PtRenderParams* p, RenderArgs* ra)
     ra->n_tiles = ra->tiles_x * tiles_y;
     ra->sub_x = (tw + 7) / 8; ra->sub_y = (th + 7) / 8;
     const int owned = (ra->n_tiles - p->shard_index + sc - 1) / sc;     // tiles t with t % sc == shard_index
-    ra->n_wave_tiles = owned * ra->sub_x * ra->sub_y;
+    const int64_t wave_tiles = (int64_t)owned * ra->sub_x * ra->sub_y;
+    // pixel slots are counted in 32 bits (64 per wave tile): tiles much smaller than 8x8 on a huge frame would wrap them
+    if (wave_tiles > ((int64_t)1 << 25)) return fail("render: too many tiles (more than 2^25 8x8 wave tiles in this shard); use larger tiles");
+    ra->n_wave_tiles = (int32_t)wave_tiles;
     ra->refill = 0;
     if (p->batch_count < 0 || p->batch_index < 0 || (p->batch_count > 0 && p->batch_index >= p->batch_count) ||
         (p->batch_count == 0 && p->batch_index != 0)) return fail("render: batch_index out of range");
@@ -930,6 +946,9 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     ra.walk_wait = 48;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
+    // One render of a scene at a time: the pixel-slot counter and the timing events belong to the
+    // scene, so a call on another stream first waits for the scene's previous render to finish.
+    if (sc->have_timing && !hip_ok(hipStreamWaitEvent(st, sc->ev_end, 0), "hipStreamWaitEvent")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
     // pixels this shard does not own must read as zero so that shards sum to the frame
     if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
@@ -975,6 +994,17 @@ extern "C" int pt_frame_finish_device(void* d_frame, size_t n_floats, int32_t to
     return PT_OK;
 }
 
+// A pass that resumed from an accumulator whose pixels do not hold `first_sample` samples (stale,
+// zero-filled, or of another render) has raised the scene's flag; read once its launch has finished.
+static bool bad_resume(PtScene* sc)
+{
+    if (!sc->bad_resume_host || !*(volatile int*)sc->bad_resume_host) return false;
+    *sc->bad_resume_host = 0;
+    pt::set_error("pt_render_pass: the accumulator does not hold the state of first_sample samples for every pixel of this shard "
+                  "(resume from the array the earlier passes of this render wrote)");
+    return true;
+}
+
 extern "C" size_t pt_accum_bytes(int32_t nx, int32_t ny)
 {
     if (nx <= 0 || ny <= 0) return 0;
@@ -994,13 +1024,15 @@ extern "C" int pt_render_pass(PtScene* sc, const PtRenderParams* p, void* d_accu
     ra.ns = first_sample + n_samples;                     // the launch stops, and normalises, at the samples done so far
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
+    if (sc->have_timing && !hip_ok(hipStreamWaitEvent(st, sc->ev_end, 0), "hipStreamWaitEvent")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
     if (first_sample == 0 &&
         !hip_ok(hipMemsetAsync(d_accum, 0, pt_accum_bytes(p->nx, p->ny), st), "hipMemsetAsync(accumulators)")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->last = PtRenderStats{};
-    if (ra.n_wave_tiles > 0) launch_pass(launch_variant(sc, ra), sc->view, ra, static_cast<PtAccumPixel*>(d_accum), first_sample, out, st);
+    if (ra.n_wave_tiles > 0)
+        launch_pass(launch_variant(sc, ra), sc->view, ra, static_cast<PtAccumPixel*>(d_accum), first_sample, out, sc->bad_resume_dev, st);
     if (!hip_ok(hipGetLastError(), "render pass launch")) return PT_ERR_HIP;
     sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
     sc->last.pipeline = PT_PIPELINE_FUSED;
@@ -1029,6 +1061,7 @@ extern "C" int pt_render_progressive(PtScene* sc, const PtRenderParams* p, float
         const int32_t n = std::min(pass_samples, p->ns - first);
         rc = pt_render_pass(sc, p, d_acc, first, n, d_out, nullptr);
         if (rc == PT_OK && !hip_ok(hipStreamSynchronize(nullptr), "render pass (synchronize)")) rc = PT_ERR_HIP;
+        if (rc == PT_OK && bad_resume(sc)) rc = PT_ERR_INVALID;
         if (rc == PT_OK && progress && progress(first + n, p->ns, user) != 0) cancelled = true;
     }
     // a cancelled render still hands back the estimate of the samples it finished
@@ -1101,6 +1134,7 @@ extern "C" int pt_render_stats(PtScene* sc, PtRenderStats* stats)
     if (!sc || !stats) { pt::set_error("pt_render_stats: null argument"); return PT_ERR_INVALID; }
     if (!sc->have_timing) { pt::set_error("pt_render_stats: no render has run on this scene"); return PT_ERR_INVALID; }
     if (!hip_ok(hipEventSynchronize(sc->ev_end), "hipEventSynchronize")) return PT_ERR_HIP;
+    if (bad_resume(sc)) return PT_ERR_INVALID;
     float k = 0, tot = 0;
     if (!hip_ok(hipEventElapsedTime(&k, sc->ev_k0, sc->ev_k1), "hipEventElapsedTime")) return PT_ERR_HIP;
     if (!hip_ok(hipEventElapsedTime(&tot, sc->ev_begin, sc->ev_end), "hipEventElapsedTime")) return PT_ERR_HIP;

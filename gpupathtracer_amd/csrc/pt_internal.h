@@ -63,6 +63,8 @@ struct PtScene {
     int n_shapes = 0, n_media = 0;
     int lbvh_nodes = 0;
     unsigned* next_slot = nullptr;      // device counter of the fused scheduler's pixel-slot pool
+    int* bad_resume_host = nullptr;     // pinned host word a progressive pass raises when its accumulator is not at first_sample
+    int* bad_resume_dev = nullptr;      // the same word as the device sees it
     // timing of the most recent render
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
     bool have_timing = false;

@@ -16,8 +16,11 @@
 //
 // Host code only.
 #include <cfloat>
+#include <climits>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -62,8 +65,15 @@ struct Reader {
     void vec3(float* v) { read(v, 12); }
 
     // Texture::Create (src/ptTexture.cu) + the deserialize members (include/ptTexture.h:64-72,113-123,160-168,215-228)
+    int tex_depth = 0;
+    struct Nest {                                             // bounds the recursion a chain of CHEK records drives
+        int& d;
+        explicit Nest(int& depth) : d(depth) { if (++d > 64) throw Fail{ "checker textures nested deeper than 64 levels" }; }
+        ~Nest() { --d; }
+    };
     int texture()
     {
+        const Nest nest(tex_depth);
         const size_t begin = off;
         const int32_t id = i32();
         if (id == ID_NULL) return -1;
@@ -84,6 +94,8 @@ struct Reader {
             t.nx = i32(); t.ny = i32();
             if (t.nx <= 0 || t.ny <= 0 || (int64_t)t.nx * t.ny > ((int64_t)1 << 28)) throw Fail{ "image texture with a bad size" };
             const size_t carried = (size_t)t.nx * t.ny, full = 3 * carried;
+            if (carried > n - off) throw Fail{ "stream ends inside an image texture (offset " + std::to_string(off) + ")" };
+            if (st->texels.size() + full > (size_t)INT32_MAX) throw Fail{ "image textures larger than 2 GiB in total" };
             t.texel_offset = (int32_t)st->texels.size();
             st->texels.resize(st->texels.size() + full, 0);
             read(st->texels.data() + t.texel_offset, carried);
@@ -321,15 +333,21 @@ struct Writer {
     void i32(int32_t v) { write(&v, 4); }
     void f32(float v) { write(&v, 4); }
 
+    // The description comes from the caller unvalidated: every index is checked before it is followed.
     void texture(int t)
     {
         if (t < 0) { i32(ID_NULL); return; }
+        if (t >= d->n_textures || !d->textures) throw Fail{ "texture index out of range" };
         const PtTexture& x = d->textures[t];
         switch (x.type) {
         case PT_TEX_CONSTANT: i32(ID_CNST); write(x.color, 12); break;
-        case PT_TEX_CHECKER: i32(ID_CHEK); f32(x.scale); texture(x.odd); texture(x.even); break;
+        case PT_TEX_CHECKER:                                  // children precede their checker (as pt_scene_create demands): no cycles
+            if (x.odd < 0 || x.even < 0 || x.odd >= t || x.even >= t) throw Fail{ "checker children must precede the checker" };
+            i32(ID_CHEK); f32(x.scale); texture(x.odd); texture(x.even); break;
         case PT_TEX_NOISE: i32(ID_NOIS); f32(x.scale); break;
         case PT_TEX_IMAGE:                                    // nx*ny of the 3*nx*ny bytes, as ImageTexture::serialize does
+            if (x.nx <= 0 || x.ny <= 0 || x.texel_offset < 0 || !d->texels ||
+                (int64_t)x.texel_offset + (int64_t)3 * x.nx * x.ny > (int64_t)d->n_texels) throw Fail{ "image texels out of range" };
             i32(ID_IMAG); i32(x.nx); i32(x.ny); write(d->texels + x.texel_offset, (size_t)x.nx * x.ny); break;
         default: throw Fail{ "unknown texture type" };
         }
@@ -337,6 +355,7 @@ struct Writer {
     void material(int m)
     {
         if (m < 0) { i32(ID_NULL); return; }
+        if (m >= d->n_materials || !d->materials) throw Fail{ "material index out of range" };
         const PtMaterial& x = d->materials[m];
         switch (x.type) {
         case PT_MAT_LAMBERTIAN: i32(ID_LAMB); texture(x.texture); break;
@@ -378,6 +397,7 @@ struct Writer {
         case PT_SHAPE_TRIANGLE: {                             // src/ptTriangle.cu:114-131
             i32(ID_TRIANGLE); write(p, 36);
             PtTriUV uv{};
+            if (s.tri_uv >= d->n_tri_uvs || (s.tri_uv >= 0 && !d->tri_uvs)) throw Fail{ "tri_uv index out of range" };
             if (s.tri_uv >= 0) uv = d->tri_uvs[s.tri_uv];
             write(&uv, 24);
             material(s.material);
@@ -419,8 +439,12 @@ struct Writer {
     }
     void shape(int index)
     {
-        if (index < 0 || index >= d->n_shapes) throw Fail{ "shape index out of range" };
-        wrapped(d->shapes[index], 0);
+        if (index < 0 || index >= d->n_shapes || !d->shapes) throw Fail{ "shape index out of range" };
+        const PtShape& s = d->shapes[index];
+        if (s.xform_count < 0 || s.xform_first < 0 || (int64_t)s.xform_first + s.xform_count > (int64_t)d->n_xforms ||
+            (s.xform_count > 0 && !d->xforms)) throw Fail{ "shape wrapper range out of bounds" };
+        if (s.xform_count > 64) throw Fail{ "more than 64 wrappers around a shape" };
+        wrapped(s, 0);
     }
 };
 
@@ -463,12 +487,18 @@ extern "C" int pt_scene_desc_from_stream(const void* data, size_t size, uint32_t
             if (r.n - r.off >= 12) r.read(c, 12);
             if (flags & PT_STREAM_KEEP_AMBIENT_COLOR) std::memcpy(st->desc.ambient_color, c, 12);
         } else throw Fail{ "unknown ambient light id " + std::to_string(amb) };
+        st->desc.accel = PT_ACCEL_LIST;
+        st->finalize();
     } catch (const Fail& f) {
         delete st;
         return fail("pt_scene_desc_from_stream: " + f.msg, (f.msg.find("not supported") != std::string::npos) ? PT_ERR_UNSUPPORTED : PT_ERR_INVALID);
+    } catch (const std::bad_alloc&) {                         // nothing may unwind across the C ABI
+        delete st;
+        return fail("pt_scene_desc_from_stream: out of memory", PT_ERR_OOM);
+    } catch (const std::exception& e) {
+        delete st;
+        return fail(std::string("pt_scene_desc_from_stream: ") + e.what(), PT_ERR_INVALID);
     }
-    st->desc.accel = PT_ACCEL_LIST;
-    st->finalize();
     *out_desc = &st->desc;
     return PT_OK;
 }
@@ -479,13 +509,15 @@ extern "C" int pt_scene_desc_to_stream(const PtSceneDesc* d, void* buffer, size_
     Writer w{ d, static_cast<uint8_t*>(buffer), buffer ? capacity : 0 };
     size_t mark[5] = { 0, 0, 0, 0, 0 };
     try {
+        if (d->n_world < 0 || (d->n_world > 0 && !d->world) || d->n_lights < 0 || (d->n_lights > 0 && !d->lights))
+            throw Fail{ "world or light list missing" };
         w.i32(ID_LIST);                                       // world->serialize, src/ptHitableList.cu:52-65
         w.i32(d->n_world);
         for (int i = 0; i < d->n_world; i++) {
             const PtObject& o = d->world[i];
             if (o.type == PT_OBJ_SHAPE) w.shape(o.index);
             else if (o.type == PT_OBJ_MEDIUM) {               // include/ptMedium.h:62-78
-                if (o.index < 0 || o.index >= d->n_media) throw Fail{ "medium index out of range" };
+                if (o.index < 0 || o.index >= d->n_media || !d->media) throw Fail{ "medium index out of range" };
                 const PtMedium& m = d->media[o.index];
                 w.i32(ID_MEDIUM);
                 w.shape(m.boundary);
@@ -514,6 +546,8 @@ extern "C" int pt_scene_desc_to_stream(const PtSceneDesc* d, void* buffer, size_
         mark[4] = w.off;
     } catch (const Fail& f) {
         return fail("pt_scene_desc_to_stream: " + f.msg, (f.msg.find("not supported") != std::string::npos) ? PT_ERR_UNSUPPORTED : PT_ERR_INVALID);
+    } catch (const std::exception& e) {                       // nothing may unwind across the C ABI
+        return fail(std::string("pt_scene_desc_to_stream: ") + e.what(), PT_ERR_INVALID);
     }
     *out_size = w.off;
     if (section_sizes) for (int i = 0; i < 4; i++) section_sizes[i] = mark[i + 1] - mark[i];

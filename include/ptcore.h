@@ -255,7 +255,10 @@ void pt_scene_destroy(PtScene* scene);
 int  pt_render(PtScene* scene, const PtRenderParams* params, float* out_rgb);
 
 /* Same, but d_out_rgb is device memory on the scene's device and the work is queued on
- * hip_stream (a hipStream_t, NULL = default stream) without a host sync. */
+ * hip_stream (a hipStream_t, NULL = default stream) without a host sync.  A scene renders one
+ * frame at a time: its pixel-slot counter and timing events are per scene, so a call first makes
+ * hip_stream wait for the scene's previous render (whatever stream that ran on).  To overlap
+ * renders, create one scene per stream. */
 int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_rgb, void* hip_stream);
 
 /* Closest hit of world->hit(ray, 0.001f, FLT_MAX) (src/ptMain.cu:104) for n rays:
@@ -297,7 +300,11 @@ typedef struct PtAccumPixel {
 size_t pt_accum_bytes(int32_t nx, int32_t ny);
 /* Samples [first_sample, first_sample + n_samples) of every pixel this shard owns; params->ns is
  * the total the render is heading for.  first_sample == 0 clears d_accum first; otherwise d_accum
- * must hold the state left by the passes up to first_sample.  d_out_rgb receives the estimate. */
+ * must hold the state left by the passes up to first_sample.  d_out_rgb receives the estimate.
+ * The launch is queued; a pass that finds an owned pixel whose PtAccumPixel.samples differs from
+ * first_sample (a stale, zero-filled or foreign array) raises a flag that the next pt_render_stats
+ * on the scene -- which waits for the launch -- reports as PT_ERR_INVALID, and pt_render_progressive
+ * checks after every pass. */
 int  pt_render_pass(PtScene* scene, const PtRenderParams* params, void* d_accum,
                     int32_t first_sample, int32_t n_samples, void* d_out_rgb, void* hip_stream);
 /* Whole render in passes of pass_samples with a callback after each (samples done, total, user);

@@ -219,6 +219,11 @@ def test_bad_render_arguments_are_errors():
         with pytest.raises(pt.PtError) as e:
             sc.render(**kw)
         assert e.value.code == abi.ERR_INVALID
+    # 1x1 tiles on an 8192^2 frame would need more pixel slots than the 32-bit slot counter holds: refused, nothing is launched
+    small = pt.DeviceBuffer(64)
+    with pytest.raises(pt.PtError) as e:
+        sc.render_device(small.ptr, 8192, 8192, 1, tile=(1, 1))
+    assert e.value.code == abi.ERR_INVALID and "tiles" in str(e.value)
 
 
 @pytest.mark.parametrize("name,aspect,nx,ny,ns", SCENES)
@@ -375,6 +380,22 @@ def test_progressive_passes_equal_one_launch(oracle):
     for bad in ((-1, 2), (0, 0), (10, 2)):
         with pytest.raises(pt.PtError):
             sc.render_pass(acc.ptr, bad[0], bad[1], frame.ptr, nx, ny, ns)
+    # resuming from an accumulator that is not where first_sample says: reported once the launch has run
+    sc.render_pass(acc.ptr, 0, 3, frame.ptr, nx, ny, ns)
+    assert sc.stats().paths == nx * ny * 3
+    sc.render_pass(acc.ptr, 5, 2, frame.ptr, nx, ny, ns)              # the array holds 3 samples, not 5
+    with pytest.raises(pt.PtError) as e:
+        sc.stats()
+    assert e.value.code == abi.ERR_INVALID and "accumulator" in str(e.value)
+    zero = pt.DeviceBuffer(pt.accum_bytes(nx, ny))
+    zero.from_host(np.zeros(pt.accum_bytes(nx, ny) // 4, np.uint32))
+    sc.render_pass(zero.ptr, 2, 2, frame.ptr, nx, ny, ns)             # a zero-filled array
+    with pytest.raises(pt.PtError):
+        sc.stats()
+    sc.render_pass(acc.ptr, 0, 3, frame.ptr, nx, ny, ns)              # and the scene is usable afterwards
+    sc.render_pass(acc.ptr, 3, 8, frame.ptr, nx, ny, ns)
+    assert sc.stats().paths == nx * ny * 8
+    assert_bit_exact(frame.to_host().reshape(ny, nx, 3), oracle.render(d, nx, ny, ns), "after a refused resume")
 
 
 def test_sample_batches_are_a_labelled_departure(oracle):

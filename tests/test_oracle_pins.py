@@ -118,3 +118,14 @@ def test_oracle_regression_hashes(oracle):
         d = pt.builtin_scene(name, float(aspect))
         img = oracle.render(d, int(nx), int(ny), int(ns))
         assert "%016x" % oracle.fnv1a(img) == want, key
+
+
+@pytest.mark.xfail(reason="the survey's whole-image FNV-1a hashes have not been reproduced under any hash convention tried "
+                          "(listed in golden/survey_pins.json); image content stays 'parity unpinned'", strict=False)
+@pytest.mark.parametrize("key,name,aspect,nx,ny,ns", [("rtiow_200x100x16", "random", 2.0, 200, 100, 16),
+                                                      ("cornell_128x128x16", "cornell", 1.0, 128, 128, 16),
+                                                      ("final_192x108x16", "final", 16 / 9, 192, 108, 16)])
+def test_survey_image_hashes(oracle, key, name, aspect, nx, ny, ns):
+    """Not a gate: shows up as XPASS the day a convention (or a fix of the oracle) reproduces a hash."""
+    img = oracle.render(pt.builtin_scene(name, aspect), nx, ny, ns)
+    assert "%016x" % oracle.fnv1a(img) == PINS["image_hashes_not_reproduced"][key]

@@ -156,3 +156,50 @@ def test_mutated_streams_never_crash():
         if rc == abi.OK:
             lib.pt_scene_destroy(h)
     assert outcomes["refused"] > 100 and outcomes["accepted"] > 100
+
+
+def test_hostile_streams_and_descriptions_are_errors_not_crashes():
+    """Inputs built to exhaust the host rather than to be wrong in one field: a chain of CHEK records
+    deep enough to overflow the stack by recursion, an IMAG header that announces far more texels
+    than the stream holds, and descriptions whose indices point outside their arrays or at themselves."""
+    import ctypes as C
+    from gpupathtracer_amd import _abi as A
+    from tests._desc_tools import OwnedDesc
+    sphere_head = i32(1) + i32(1) + i32(2) + f32(0, 0, 0, 1) + i32(fourcc("LAMB"))
+    deep = sphere_head + (i32(fourcc("CHEK")) + f32(1.0)) * 200_000
+    with pytest.raises(pt.PtError) as e:
+        pt.scene_from_stream(deep)
+    assert e.value.code == abi.ERR_INVALID and "nested" in str(e.value)
+    huge = sphere_head + i32(fourcc("IMAG")) + i32(16384) + i32(16384) + b"\0" * 64     # 768 MiB announced, 64 bytes present
+    with pytest.raises(pt.PtError) as e:
+        pt.scene_from_stream(huge)
+    assert e.value.code == abi.ERR_INVALID and "image" in str(e.value)
+    # several images whose offsets would pass 2 GiB are refused before anything is allocated for them
+    lib = pt.library()
+    size, sections = C.c_size_t(0), (C.c_size_t * 4)()
+
+    def to_stream_rc(g):
+        g.finalize()
+        return lib.pt_scene_desc_to_stream(g.ptr, None, 0, C.byref(size), sections)
+
+    g = OwnedDesc(pt.builtin_scene("random", 2.0))
+    assert to_stream_rc(g) == abi.OK
+    chk = next(i for i, t in enumerate(g.lists["textures"]) if t.type == abi.TEX_CHECKER)
+    g.lists["textures"][chk].odd = chk                                  # a checker that is its own child
+    assert to_stream_rc(g) == abi.ERR_INVALID
+    for field, arr, bad in (("material", "shapes", 10_000), ("xform_count", "shapes", 7), ("xform_first", "shapes", -3),
+                            ("texture", "materials", 99), ("texture", "materials", 2_000_000_000)):
+        g = OwnedDesc(pt.builtin_scene("cornell", 1.0))
+        setattr(g.lists[arr][1], field, bad)
+        assert to_stream_rc(g) == abi.ERR_INVALID, (field, bad)
+    g = OwnedDesc(pt.builtin_scene("trimesh", 1.0))
+    tri = next(s for s in g.lists["shapes"] if s.type == abi.SHAPE_TRIANGLE)
+    tri.tri_uv = 5_000_000
+    assert to_stream_rc(g) == abi.ERR_INVALID
+    tex = np.zeros((4, 4, 3), np.uint8)
+    g = OwnedDesc(pt.builtin_scene("final", 1.5, earth_rgb=tex))
+    img = next(t for t in g.lists["textures"] if t.type == abi.TEX_IMAGE)
+    img.nx = 30000
+    g.lists["bvhs"], g.lists["bvh_nodes"] = [], []
+    g.lists["world"] = [o for o in g.lists["world"] if o.type != abi.OBJ_BVH]
+    assert to_stream_rc(g) == abi.ERR_INVALID
