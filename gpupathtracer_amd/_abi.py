@@ -104,7 +104,7 @@ assert C.sizeof(PtRenderParams) == 64
 
 # Every symbol include/ptcore.h declares.
 EXPORTS = [
-    "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
+    "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_render_device_noalloc",
     "pt_trace_closest", "pt_render_stats", "pt_render_on_devices", "pt_frame_finish_device", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
     "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",

@@ -45,6 +45,7 @@ def library():
     lib.pt_scene_destroy.restype = None
     lib.pt_render.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p]
     lib.pt_render_device.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_void_p]
+    lib.pt_render_device_noalloc.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_void_p]
     lib.pt_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.pt_render_stats.argtypes = [C.c_void_p, P(A.PtRenderStats)]
     lib.pt_scene_lbvh_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -318,6 +319,12 @@ class Scene:
         p = make_params(nx, ny, ns, max_depth, **kw)
         _check(library().pt_render_device(self._h, C.byref(p), C.c_void_p(d_out_ptr),
                                           C.c_void_p(stream) if stream else None))
+
+    def render_device_noalloc(self, d_out_ptr, nx, ny, ns, max_depth=25, stream=None, **kw):
+        """render_device through the entry point that allocates no device memory (static slot counter)."""
+        p = make_params(nx, ny, ns, max_depth, **kw)
+        _check(library().pt_render_device_noalloc(self._h, C.byref(p), C.c_void_p(d_out_ptr),
+                                                  C.c_void_p(stream) if stream else None))
 
     def render_pass(self, d_accum_ptr, first_sample, n_samples, d_out_ptr, nx, ny, ns, max_depth=25, stream=None, **kw):
         """Samples [first_sample, first_sample + n_samples) of a render of ns samples (device buffers)."""

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -542,6 +543,16 @@ std::vector<float> signature_table(const PtSceneDesc* d)
 
 // ---- host side of the C ABI --------------------------------------------------------------------------
 
+// Scratch of pt_render_device_noalloc: the pixel-slot counter of the persistent-lane schedules in
+// device memory that exists from the moment the library's code object is loaded, so the call needs
+// no hipMalloc.  One copy per GPU; every such call on a GPU uses that GPU's copy.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: g_scratch_ptr[] holds the device addresses.
+constexpr size_t PT_SCRATCH_BYTES = 256;
+static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
+constexpr int PT_MAX_DEVICES = 64;
+static unsigned* g_scratch_ptr[PT_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
 namespace {
 
 bool hip_ok(hipError_t e, const char* what)
@@ -551,6 +562,22 @@ bool hip_ok(hipError_t e, const char* what)
     pt::set_error(msg.c_str());
     (void)hipGetLastError();      // the runtime keeps the last error until it is read: do not let it surface in a later call
     return false;
+}
+
+// Device address of this GPU's copy of `scratch`; looked up once per device, with that device current.
+unsigned* scratch_on_device(int device)
+{
+    if (device < 0 || device >= PT_MAX_DEVICES) { pt::set_error("device index beyond the library's table of scratch addresses"); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int current = -1;
+        if (!hip_ok(hipGetDevice(&current), "hipGetDevice")) return nullptr;
+        if (current != device) { pt::set_error("the scene's device must be the current device"); return nullptr; }
+        void* ptr = nullptr;
+        if (!hip_ok(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)")) return nullptr;
+        g_scratch_ptr[device] = static_cast<unsigned*>(ptr);
+    }
+    return g_scratch_ptr[device];
 }
 
 template <class T>
@@ -841,6 +868,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         if (!hip_ok(hipHostGetDevicePointer(&dev, flag, 0), "hipHostGetDevicePointer")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
         sc->bad_resume_dev = static_cast<int*>(dev);
     }
+    if (!scratch_on_device(sc->device)) { pt_scene_destroy(sc); return PT_ERR_HIP; }     // set-up for pt_render_device_noalloc
     ok = hip_ok(hipEventCreate(&sc->ev_begin), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_k0), "hipEventCreate")
       && hip_ok(hipEventCreate(&sc->ev_k1), "hipEventCreate") && hip_ok(hipEventCreate(&sc->ev_end), "hipEventCreate");
     if (!ok) { pt_scene_destroy(sc); return PT_ERR_HIP; }
@@ -916,9 +944,10 @@ int launch_variant(const PtScene* sc, const RenderArgs& ra)
 }
 }  // namespace
 
-extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream)
+// slot_counter: the device word the persistent-lane schedules count pixel slots in -- the scene's own
+// allocation, or this GPU's static scratch for the call that may not allocate.
+static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream, unsigned* slot_counter, bool no_alloc)
 {
-    if (!sc || !p || !d_out_rgb) { pt::set_error("pt_render_device: null argument"); return PT_ERR_INVALID; }
     RenderArgs ra;
     if (!make_args(p, &ra)) return PT_ERR_INVALID;
     if (p->pipeline != PT_PIPELINE_DEFAULT && p->pipeline != PT_PIPELINE_FUSED && p->pipeline != PT_PIPELINE_WAVEFRONT) {
@@ -957,13 +986,17 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     if (p->pipeline == PT_PIPELINE_WAVEFRONT && (ra.seed_offset != 0 || ra.raw_sum)) {
         pt::set_error("render: sample batches run on the fused pipeline"); return PT_ERR_UNSUPPORTED;
     }
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT && no_alloc) {
+        pt::set_error("pt_render_device_noalloc: the staged pipeline allocates its queues; use the fused pipeline"); return PT_ERR_UNSUPPORTED;
+    }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT) {
         const int rc = pt::render_wavefront(sc, ra, out, st);       // host-driven rounds; blocks
         if (rc != PT_OK) return rc;
         sc->last.pipeline = PT_PIPELINE_WAVEFRONT;
     } else {
-        if (!hip_ok(hipMemsetAsync(sc->next_slot, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
-        if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, sc->next_slot, st);
+        // the counter keeps the last call's final value: it starts every call at zero
+        if (!hip_ok(hipMemsetAsync(slot_counter, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
+        if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, st);
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
@@ -975,6 +1008,38 @@ extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_ou
     sc->have_timing = true;
     sc->last.paths = owned_pixels(p, ra) * (uint64_t)p->ns;
     return PT_OK;
+}
+
+extern "C" int pt_render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream)
+{
+    if (!sc || !p || !d_out_rgb) { pt::set_error("pt_render_device: null argument"); return PT_ERR_INVALID; }
+    return render_device(sc, p, d_out_rgb, hip_stream, sc->next_slot, false);
+}
+
+// pt_render_device for callers that cannot allocate device memory (see include/ptcore.h).  Calls no
+// hipMalloc / hipFree: the slot counter is this GPU's static scratch, whose address was looked up
+// when the scene was created.
+extern "C" int pt_render_device_noalloc(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, void* hip_stream)
+{
+    if (!sc || !p || !d_out_rgb) { pt::set_error("pt_render_device_noalloc: null argument"); return PT_ERR_INVALID; }
+    // the scratch holds one 32-bit slot counter: 64 slots per 8x8 wave tile, so at most 2^25 wave tiles per call
+    const int64_t tw = p->tile_w > 0 ? p->tile_w : 8, th = p->tile_h > 0 ? p->tile_h : 8;
+    if (p->nx > 0 && p->ny > 0) {
+        const int64_t tiles = ((p->nx + tw - 1) / tw) * ((p->ny + th - 1) / th);
+        const int64_t shards = p->shard_count > 0 ? p->shard_count : 1;
+        const int64_t wave_tiles = ((tiles + shards - 1) / shards) * ((tw + 7) / 8) * ((th + 7) / 8);
+        if (wave_tiles > PT_NOALLOC_MAX_WAVE_TILES) {
+            pt::set_error("pt_render_device_noalloc: the shard has more than PT_NOALLOC_MAX_WAVE_TILES (2^25) 8x8 wave tiles; "
+                          "the static slot counter cannot number its pixel slots");
+            return PT_ERR_INVALID;
+        }
+    }
+    int current = -1;
+    if (!hip_ok(hipGetDevice(&current), "hipGetDevice")) return PT_ERR_HIP;
+    if (current != sc->device) { pt::set_error("pt_render_device_noalloc: the scene's device must be the current device"); return PT_ERR_INVALID; }
+    unsigned* counter = scratch_on_device(sc->device);       // stored at pt_scene_create; no lookup happens here
+    if (!counter) return PT_ERR_HIP;
+    return render_device(sc, p, d_out_rgb, hip_stream, counter, true);
 }
 
 __global__ __launch_bounds__(256) void k_frame_finish(float* __restrict__ frame, size_t n, float inv_ns)

@@ -261,6 +261,21 @@ int  pt_render(PtScene* scene, const PtRenderParams* params, float* out_rgb);
  * renders, create one scene per stream. */
 int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_rgb, void* hip_stream);
 
+/* pt_render_device for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * Same arguments, same frame bit for bit; the call itself performs no hipMalloc / hipFree.  The
+ * one piece of device memory the fused pipeline needs beyond the scene and the frame -- the 32-bit
+ * pixel-slot counter of the persistent-lane schedules (PT_SCHEDULE_REFILL / _WALK) -- lives in a
+ * 256-byte array that is part of the library's device code, one copy per GPU, instead of in memory
+ * the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its queues:
+ * PT_ERR_UNSUPPORTED); at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
+ * counter can number its pixel slots (PT_ERR_INVALID beyond); the scene's device must be current.
+ * The counter is cleared at the start of every call.  All calls on one GPU share that GPU's
+ * array, whatever the scene or stream: calls that overlap on one GPU race on it and trace pixels
+ * twice or not at all -- run them one after another (one stream, or events between streams). */
+#define PT_NOALLOC_MAX_WAVE_TILES (1 << 25)
+int  pt_render_device_noalloc(PtScene* scene, const PtRenderParams* params, void* d_out_rgb, void* hip_stream);
+
 /* Closest hit of world->hit(ray, 0.001f, FLT_MAX) (src/ptMain.cu:104) for n rays:
  * prim_id = winning shape index (or PT_ID_MEDIUM_BASE+m, or PT_ID_MISS), t = rec.t.
  * Host pointers; blocking. */
