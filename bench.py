@@ -7,9 +7,11 @@ complete render of the frame: every rank traces its 8x8-tile shard of the image 
 already resident in HBM, then the shards are summed onto rank 0 with one RCCL reduce over xGMI.
 A path is one camera sample (one color() call of the reference, src/ptMain.cu:161).
 
-torch.distributed is used for rendezvous, barriers and the max-over-ranks clock only (gloo, CPU):
-the wheel's bundled HIP runtime and the system ROCm runtime this library links cannot both drive
-the GPU in one process, so device memory, streams and the RCCL communicator live in the library.
+The ranks load no GPU runtime but the one libptcore.so links: RCCL's unique id travels from rank 0
+to the others through a directory on the local file system (gpupathtracer_amd/hostgroup.py), and
+barriers and the max-over-ranks clock go through the library's own RCCL communicator.  N > 1 thus
+runs on the same HIP and RCCL as N = 1; the line reports which runtime files are mapped and the
+run fails if two HIP runtimes are.
 """
 import argparse
 import json
@@ -38,6 +40,15 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "pmc_cornell1024x512_k_
 PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
+def library_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +60,7 @@ def main():
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--cpu-spp", type=int, default=512, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frame-hash", action="store_true", help="add the SHA-1 of the final frame on rank 0 to the result line")
     ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles",
                     help="tiles: whole pixels per rank, the reference's image bit for bit (default).  samples: every rank "
                          "traces spp/N samples of every pixel from its own seeds -- not the reference's random sequence, "
@@ -61,15 +73,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
     import gpupathtracer_amd as pt
+    from gpupathtracer_amd import hostgroup
 
     n_dev = pt.device_count()
     if n_dev < 1:
@@ -82,26 +87,27 @@ def main():
     n_floats = 3 * nx * ny
     frame = pt.DeviceBuffer(n_floats * 4)
 
+    # N > 1: rank 0's RCCL id reaches the others through files; everything after that is RCCL.
+    # PT_BENCH_COLLECTIVE=files keeps barriers, clock and the frame sum on files too: a rehearsal of
+    # this script's logic on a box whose ranks share one GPU, where RCCL cannot connect them.
     collective = "none"
-    comm = None
+    group = comm = None
     if world > 1:
-        import torch
-        uid = [pt.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        try:
-            if os.environ.get("PT_BENCH_COLLECTIVE", "rccl") != "rccl":      # rehearsal on a one-GPU box
-                raise pt.PtError(0, "RCCL disabled by PT_BENCH_COLLECTIVE")
-            comm = pt.Comm(uid[0], rank, world)
+        group = hostgroup.FileGroup(rank, world)
+        uid = group.broadcast("rccl_unique_id", pt.Comm.unique_id() if rank == 0 else None)
+        want_rccl = os.environ.get("PT_BENCH_COLLECTIVE", "rccl") == "rccl"
+        if want_rccl:
+            try:
+                comm = pt.Comm(uid, rank, world)
+            except pt.PtError as e:      # keep the run alive, but say so in the result line
+                sys.stderr.write("[bench] rank %d: RCCL communicator failed (%s)\n" % (rank, e))
+        if group.allreduce_min_int(1 if comm is not None else 0) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            collective = "files-host-reduce" + ("" if not want_rccl else " (RCCL failed)")
+        else:
             collective = "rccl-reduce"
-        except pt.PtError as e:      # keep the run alive, but say so in the result line
-            sys.stderr.write("[bench] RCCL communicator failed (%s); gathering frames through host/gloo\n" % e)
-            collective = "gloo-host-reduce"
-        flag = torch.tensor([1 if comm is not None else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
-            collective = "gloo-host-reduce"
 
     kernel_ms = []
 
@@ -120,17 +126,17 @@ def main():
             if comm is not None:
                 comm.reduce_frame(frame.ptr, n_floats, root=0)
             else:
-                import torch
-                host = torch.from_numpy(frame.to_host())
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if samples and rank == 0:
-                    frame.from_host(host.numpy())
+                total = group.reduce_sum(frame.to_host(), root=0)
+                if rank == 0:
+                    frame.from_host(total)
             if samples and rank == 0:
                 pt.frame_finish(frame.ptr, n_floats, args.spp)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
+        elif group is not None:
+            group.barrier()
 
     def timed(samples, record):
         for _ in range(args.warmup):
@@ -143,14 +149,17 @@ def main():
         pt.synchronize()
         barrier()
         dt = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-            tt = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        if comm is not None:
+            dt = comm.allreduce_max(dt)
+        elif group is not None:
+            dt = group.allreduce_max(dt)
         return dt
 
     dt = timed(by_samples, True)
+    frame_sha1 = None
+    if args.frame_hash and rank == 0:       # the headline's frame, before the second sharding below overwrites it
+        import hashlib
+        frame_sha1 = hashlib.sha1(frame.to_host().tobytes()).hexdigest()
     # Beside the headline (tile shards: the reference's image bit for bit), the same frame with the
     # samples of every pixel split over the ranks: the other sharding the task names, equal to the
     # reference's image up to sampling noise only.  Reported, never used for `value`.
@@ -168,13 +177,20 @@ def main():
         roofline = None
         if flop is not None:
             achieved = shard_paths * flop / (k_ms * 1e-3) / 1e12
-            traffic = None
+            # HBM bytes per launch come from a committed rocprofv3 PMC pass (counters cannot be read inside
+            # this process); the file names the build it profiled, and a number from another build is not reported
+            traffic, traffic_note = None, "no PMC pass for this workload"
             if args.scene == "cornell" and nx == 1024 and ny == 1024 and world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
                 with open(PMC_TRAFFIC_FILE) as f:
-                    d = json.load(f)["_derived"]
-                traffic = d["fetch_bytes_per_launch_corrected_x2"] + d["write_kib_per_launch"] * 1024.0
+                    pmc = json.load(f)
+                if pmc.get("_libptcore_sha256") == library_sha256(pt.library_path()):
+                    d = pmc["_derived"]
+                    traffic = d["fetch_bytes_per_launch_corrected_x2"] + d["write_kib_per_launch"] * 1024.0
+                    traffic_note = "FETCH_SIZE x2 + WRITE_SIZE per launch, %s (%s)" % (os.path.relpath(PMC_TRAFFIC_FILE, ROOT), pmc.get("_command", ""))
+                else:
+                    traffic_note = "the committed PMC pass profiled another build of libptcore.so; not reported"
             roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_VALU_TFLOPS, "traffic": traffic,
+                        "frac": achieved / PEAK_VALU_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                         "kernel": "k_render_refill" if scene.stats().schedule == 2 else "k_render_tiles",
                         "kernel_ms": k_ms, "flop_per_path": flop, "paths_per_launch": shard_paths,
                         "peak_note": "fp32 VALU, one add/mul per lane per cycle, no FMA credit (parity forbids contraction); compares, "
@@ -184,13 +200,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from tests import _oracle
             orc = _oracle.load()
-            threads = max(1, min(16, os.cpu_count() or 1))
+            # every hardware thread this job may use: the box hands a one-GPU job a share of its CPUs and says
+            # so in OMP_NUM_THREADS (os.cpu_count() reports the whole machine there)
+            visible = os.cpu_count() or 1
+            share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+            threads = max(1, min(visible, share) if share > 0 else visible)
             c0 = time.perf_counter()
             orc.render(desc, nx, ny, args.cpu_spp, args.depth, threads=threads)
             cdt = time.perf_counter() - c0
             cpu = {"value": nx * ny * args.cpu_spp / cdt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
-                   "sample": "%s %dx%d at %d spp, depth %d, OpenMP rows over %d threads" %
-                             (args.scene, nx, ny, args.cpu_spp, args.depth, threads)}
+                   "host_threads_visible": visible, "host_thread_share": share if share > 0 else None,
+                   "sample": "%s %dx%d at %d spp, depth %d, OpenMP rows over %d threads (all this job may use; nproc says %d)" %
+                             (args.scene, nx, ny, args.cpu_spp, args.depth, threads, visible)}
         result = {
             "metric": "Mpaths/s whole node, Cornell 1024^2 4096spp",
             "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,18 +224,25 @@ def main():
                        "pipeline": "fused", "collective": collective},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        hip_libs, rccl_libs = hostgroup.mapped_runtimes()
+        result["runtime"] = {"hip": hip_libs, "rccl": rccl_libs, "torch_loaded": "torch" in sys.modules}
+        if frame_sha1 is not None:
+            result["frame_sha1"] = frame_sha1
         if dt_samples is not None:
             result["sample_batch_sharding"] = {
                 "value": paths_per_step * args.steps / dt_samples / 1e6, "unit": "Mpaths/s", "ms_per_step": dt_samples / args.steps * 1e3,
                 "note": "every rank traces spp/N samples of every pixel from its own seeds, raw sums reduced, finished on rank 0; "
                         "not the reference's random sequence (PSNR-tested), not part of `value`"}
+    hip_libs, _ = hostgroup.mapped_runtimes()
+    barrier()
     if comm is not None:
         comm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.close()
     if result is not None:
         print(json.dumps(result), flush=True)
+    if len(hip_libs) > 1:        # two HIP runtimes in one process: whatever was measured, it was not the N = 1 configuration
+        raise SystemExit("bench.py: rank %d has more than one HIP runtime mapped: %s" % (rank, hip_libs))
 
 
 if __name__ == "__main__":

@@ -75,6 +75,8 @@ def library():
     lib.pt_comm_unique_id.argtypes = [C.c_void_p]
     lib.pt_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
     lib.pt_comm_reduce_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    lib.pt_comm_barrier.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pt_comm_allreduce_max_f64.argtypes = [C.c_void_p, P(C.c_double), C.c_void_p]
     lib.pt_comm_destroy.argtypes = [C.c_void_p]
     lib.pt_comm_destroy.restype = None
     lib.pt_libm_eval.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
@@ -169,6 +171,14 @@ class Comm:
     def reduce_frame(self, dev_ptr, n_floats, root=0, stream=None):
         _check(library().pt_comm_reduce_frame(self._h, C.c_void_p(dev_ptr), n_floats, root,
                                               C.c_void_p(stream) if stream else None))
+
+    def barrier(self, stream=None):
+        _check(library().pt_comm_barrier(self._h, C.c_void_p(stream) if stream else None))
+
+    def allreduce_max(self, value, stream=None):
+        v = C.c_double(float(value))
+        _check(library().pt_comm_allreduce_max_f64(self._h, C.byref(v), C.c_void_p(stream) if stream else None))
+        return float(v.value)
 
     def close(self):
         if self._h is not None:

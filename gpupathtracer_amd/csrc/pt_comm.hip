@@ -47,6 +47,7 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
 struct PtComm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    double* d_scalar = nullptr;      // one device double for the barrier and the scalar reductions
 };
 
 extern "C" int pt_set_device(int device)
@@ -110,6 +111,8 @@ extern "C" int pt_comm_init(const void* id128, int rank, int world, PtComm** out
     c->rank = rank; c->world = world;
     ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { delete c; return nccl_err(r, "ncclCommInitRank"); }
+    hipError_t e = hipMalloc((void**)&c->d_scalar, 64);
+    if (e != hipSuccess) { (void)ncclCommDestroy(c->comm); delete c; hip_err(e, "hipMalloc(comm scalar)"); return PT_ERR_OOM; }
     *out = c;
     return PT_OK;
 }
@@ -122,10 +125,34 @@ extern "C" int pt_comm_reduce_frame(PtComm* c, void* d_frame, size_t n_floats, i
     return PT_OK;
 }
 
+// max over the ranks of one double, on every rank; blocks until the result is back on the host.
+extern "C" int pt_comm_allreduce_max_f64(PtComm* c, double* inout, void* hip_stream)
+{
+    if (!c || !inout) { pt::set_error("pt_comm_allreduce_max_f64: bad arguments"); return PT_ERR_INVALID; }
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = hipMemcpyAsync(c->d_scalar, inout, sizeof(double), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_err(e, "hipMemcpyAsync(scalar)");
+    ncclResult_t r = ncclAllReduce(c->d_scalar, c->d_scalar, 1, ncclDouble, ncclMax, c->comm, st);
+    if (r != ncclSuccess) return nccl_err(r, "ncclAllReduce(max)");
+    e = hipMemcpyAsync(inout, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_err(e, "hipMemcpyAsync(scalar)");
+    e = hipStreamSynchronize(st);
+    return e == hipSuccess ? PT_OK : hip_err(e, "hipStreamSynchronize");
+}
+
+// Returns on every rank only after every rank has called it (and after the work queued before it
+// on hip_stream has finished): an all-reduce of one value followed by a stream synchronize.
+extern "C" int pt_comm_barrier(PtComm* c, void* hip_stream)
+{
+    double one = 1.0;
+    return pt_comm_allreduce_max_f64(c, &one, hip_stream);
+}
+
 extern "C" void pt_comm_destroy(PtComm* c)
 {
     if (!c) return;
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
     delete c;
 }
 

@@ -1,0 +1,131 @@
+"""One process per GPU without a second communication library in the process.
+
+The reference is a single-process, single-GPU program (src/ptMain.cu:579-653); running one process
+per GPU is this build's addition.  A launcher (``python -m torch.distributed.run``) starts the ranks
+and exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the ranks themselves only
+need (1) a way to hand RCCL's 128-byte unique id from rank 0 to the others and (2) barriers and a
+max-over-ranks clock.  (1) goes through a directory on the node's local file system, (2) through
+the RCCL communicator of ``libptcore.so`` itself (``pt_comm_barrier``, ``pt_comm_allreduce_max_f64``).
+No other GPU runtime is loaded into the process, so the library binds to the same HIP and RCCL as
+in a single-process run.
+
+``FileGroup`` also implements barrier / max / frame-sum through files alone.  That path exists for
+rehearsals on machines where RCCL cannot connect the ranks (several ranks sharing one GPU, or no
+GPU at all): slow, but it exercises the same bench logic.
+"""
+import os
+import shutil
+import time
+
+import numpy as np
+
+
+def mapped_runtimes():
+    """Paths of the HIP and RCCL runtimes mapped into this process (from /proc/self/maps)."""
+    hip, rccl = set(), set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                fields = line.split(None, 5)
+                path = fields[5].strip() if len(fields) == 6 else ""
+                base = os.path.basename(path)
+                if base.startswith("libamdhip64.so"):
+                    hip.add(os.path.realpath(path))
+                elif base.startswith("librccl.so"):
+                    rccl.add(os.path.realpath(path))
+    except OSError:
+        pass
+    return sorted(hip), sorted(rccl)
+
+
+class FileGroup:
+    """Rendezvous of `world` ranks through a directory on the local file system."""
+
+    def __init__(self, rank, world, directory=None, timeout=300.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        if directory is None:
+            # the ranks of one launch share the launcher as parent and the port it was given
+            directory = os.path.join(os.environ.get("PT_RENDEZVOUS_ROOT", "/tmp"),
+                                     "ptgroup_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        self.dir = directory
+        os.makedirs(self.dir, exist_ok=True)
+        self._seq = 0
+        self._last_file = None
+
+    # ---- small files, written atomically -------------------------------------------------------
+    def _path(self, name):
+        return os.path.join(self.dir, name)
+
+    def publish(self, name, data):
+        tmp = self._path(".%s.%d.tmp" % (name, self.rank))
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, self._path(name))
+
+    def fetch(self, name):
+        path = self._path(name)
+        deadline = time.monotonic() + self.timeout
+        delay = 0.0002
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    return f.read()
+            except FileNotFoundError:
+                if time.monotonic() > deadline:
+                    raise TimeoutError("rank %d: %s did not appear within %.0f s" % (self.rank, path, self.timeout))
+                time.sleep(delay)
+                delay = min(delay * 1.5, 0.01)
+
+    def broadcast(self, name, data=None, root=0):
+        if self.rank == root:
+            self.publish(name, data)
+            return data
+        return self.fetch(name)
+
+    # ---- collectives through files (rehearsal path) --------------------------------------------
+    def gather_all(self, tag, payload):
+        """Every rank's payload (bytes), in rank order, on every rank."""
+        self._seq += 1
+        key = "%s.%d" % (tag, self._seq)
+        mine = "%s.r%d" % (key, self.rank)
+        self.publish(mine, payload)
+        parts = [self.fetch("%s.r%d" % (key, r)) for r in range(self.world)]
+        # Every rank has published this round, so every rank has finished reading the round before
+        # (a rank publishes only after its own reads): this rank's previous file can go.
+        if self._last_file:
+            try:
+                os.remove(self._path(self._last_file))
+            except OSError:
+                pass
+        self._last_file = mine
+        return parts
+
+    def barrier(self):
+        self.gather_all("barrier", b"1")
+
+    def allreduce_max(self, value):
+        return max(float(x) for x in self.gather_all("max", repr(float(value)).encode()))
+
+    def allreduce_min_int(self, value):
+        return min(int(x) for x in self.gather_all("min", str(int(value)).encode()))
+
+    def reduce_sum(self, array, root=0):
+        """Sum of the ranks' float32 arrays on `root` (added in rank order), None elsewhere."""
+        a = np.ascontiguousarray(array, np.float32)
+        parts = self.gather_all("sum", a.tobytes())
+        if self.rank != root:
+            return None
+        total = np.zeros_like(a)
+        for p in parts:
+            total += np.frombuffer(p, np.float32).reshape(a.shape)
+        return total
+
+    def close(self):
+        """Last call of every rank: rank 0 removes the directory once everybody has left."""
+        self._seq += 1
+        key = "bye.%d" % self._seq
+        self.publish("%s.r%d" % (key, self.rank), b"1")
+        if self.rank == 0:
+            for r in range(self.world):
+                self.fetch("%s.r%d" % (key, r))
+            shutil.rmtree(self.dir, ignore_errors=True)

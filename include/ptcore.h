@@ -402,6 +402,12 @@ typedef struct PtComm PtComm;
 int  pt_comm_unique_id(void* id128);
 int  pt_comm_init(const void* id128, int rank, int world, PtComm** out_comm);
 int  pt_comm_reduce_frame(PtComm* comm, void* d_frame, size_t n_floats, int root, void* hip_stream);
+/* Host-side synchronisation of the ranks through the same communicator, so that a multi-process host
+ * needs no second communication library: a barrier (returns once every rank has called it and the
+ * work queued on hip_stream before it has finished) and the maximum of one double over the ranks
+ * (a benchmark's max-over-ranks clock).  Both block. */
+int  pt_comm_barrier(PtComm* comm, void* hip_stream);
+int  pt_comm_allreduce_max_f64(PtComm* comm, double* inout, void* hip_stream);
 void pt_comm_destroy(PtComm* comm);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */

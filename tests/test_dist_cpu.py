@@ -58,3 +58,64 @@ def test_every_pixel_has_exactly_one_owner():
         for r in range(world):
             owners += (orc.render(d, 50, 30, 1, shard_index=r, shard_count=world, tile=tile).sum(axis=2) > 0)
         assert (owners == 1).all()
+
+
+def _file_group_worker(rank, world, directory, out_path):
+    sys.path.insert(0, ROOT)
+    import gpupathtracer_amd as pt
+    from gpupathtracer_amd.hostgroup import FileGroup
+    from tests import _oracle
+    g = FileGroup(rank, world, directory=directory, timeout=120)
+    uid = g.broadcast("rccl_unique_id", bytes(range(128)) if rank == 0 else None)     # what bench.py hands round
+    assert uid == bytes(range(128))
+    assert g.allreduce_min_int(1 if rank != 1 else 0) == 0                           # one rank without a communicator: all fall back
+    assert g.allreduce_min_int(1) == 1
+    orc = _oracle.load()
+    d = pt.builtin_scene("cornell", 72 / 40)
+    for step in range(3):                                                             # bench.py's loop: render shard, sum on rank 0
+        part = orc.render(d, 72, 40, 2 + step, shard_index=rank, shard_count=world, tile=(8, 8), threads=2)
+        total = g.reduce_sum(part, root=0)
+        assert (total is None) == (rank != 0)
+        if rank == 0:
+            np.save(out_path % step, total)
+    g.barrier()
+    assert g.allreduce_max(10.0 + rank) == 10.0 + world - 1
+    assert len([f for f in os.listdir(directory) if f.startswith("sum.")]) <= world  # earlier rounds' frames are gone
+    g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_file_group_drives_the_bench_logic_without_any_gpu_runtime(world):
+    """bench.py's N > 1 host logic over its own rendezvous code (gpupathtracer_amd/hostgroup.py), as
+    plain processes: id broadcast, agreement on the fallback, shard frames summed on rank 0 equal to
+    the unsharded frame bit for bit, max-over-ranks clock, clean-up."""
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import gpupathtracer_amd as pt
+    from tests import _oracle
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as tmp:
+        directory, out = os.path.join(tmp, "group"), os.path.join(tmp, "frame%d.npy")
+        procs = [ctx.Process(target=_file_group_worker, args=(r, world, directory, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        assert not os.path.exists(directory)                                          # rank 0 removed it after the last rank left
+        d = pt.builtin_scene("cornell", 72 / 40)
+        for step in range(3):
+            full = _oracle.load().render(d, 72, 40, 2 + step)
+            np.testing.assert_array_equal(np.load(out % step).view(np.uint32), full.view(np.uint32))
+
+
+def test_mapped_runtime_report_names_one_hip_runtime():
+    """A process that loads the library and nothing else maps exactly one HIP runtime, the one the
+    library links; bench.py prints this report and refuses to pass with two."""
+    import subprocess
+    code = ("import sys, json; sys.path.insert(0, %r); import gpupathtracer_amd as pt; pt.library(); "
+            "from gpupathtracer_amd.hostgroup import mapped_runtimes; print(json.dumps([mapped_runtimes(), 'torch' in sys.modules]))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, check=True).stdout
+    (hip, rccl), torch_loaded = __import__("json").loads(out.strip().splitlines()[-1])
+    assert len(hip) == 1 and len(rccl) == 1 and not torch_loaded
+    assert "/torch/" not in hip[0] and "/torch/" not in rccl[0]
