@@ -71,6 +71,7 @@ struct SceneView {
     const int32_t*    lights;
     const LbvhNode*   lbvh;
     const float*      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
+    const float*      sig_faces;    // signature walk: SIG_FACE floats per (entry, face): the finished surface (see shade_sig); nullptr = none
     const int32_t*    lbvh_order;   // per shape: its place in the sequence of tests the in-order walk makes (nullptr: the shape index)
     const int32_t*    lbvh_group;   // per shape: the reference BVH it is a leaf of, -1 for a list entry (with lbvh_order)
     const float*      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
@@ -89,24 +90,27 @@ struct SceneView {
     float   camera[24];
 };
 
+// Vector helpers compile for the host as well: the signature tables below are filled on the host with the
+// very functions the kernels would run (IEEE add/mul/div/sqrt, no contraction: the same bits on both sides).
+#define PT_FN __host__ __device__ __forceinline__
 // ---- small vector type ------------------------------------------------------------------
 struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ float len(V3 a) { return sqrtf(sqlen(a)); }
-__device__ __forceinline__ V3 cross(V3 a, V3 b)
+PT_FN V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_FN V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_FN V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_FN V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_FN V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+PT_FN V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PT_FN V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+PT_FN V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+PT_FN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_FN float sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+PT_FN float len(V3 a) { return sqrtf(sqlen(a)); }
+PT_FN V3 cross(V3 a, V3 b)
 {
     return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ V3 unit(V3 a) { return a / len(a); }
+PT_FN V3 unit(V3 a) { return a / len(a); }
 
 struct Ray { V3 o, d; float time; };
 __device__ __forceinline__ V3 at(const Ray& r, float t) { return r.o + t * r.d; }
@@ -185,7 +189,7 @@ __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqr
 
 // ---- orthonormal basis (include/ptONB.h:27-39) ------------------------------------------------
 struct Onb { V3 u, v, w; };
-__device__ __forceinline__ Onb onb_from_w(V3 n)
+PT_FN Onb onb_from_w(V3 n)
 {
     Onb b;
     b.w = unit(n);
@@ -194,7 +198,7 @@ __device__ __forceinline__ Onb onb_from_w(V3 n)
     b.u = cross(b.w, b.v);
     return b;
 }
-__device__ __forceinline__ V3 onb_local(const Onb& b, V3 a) { return a.x * b.u + a.y * b.v + a.z * b.w; }
+PT_FN V3 onb_local(const Onb& b, V3 a) { return a.x * b.u + a.y * b.v + a.z * b.w; }
 
 // ---- camera (include/ptCamera.h:28-34) ---------------------------------------------------------
 __device__ __forceinline__ Ray camera_ray(const SceneView& sv, float s, float t, Pcg& g)
@@ -487,6 +491,7 @@ struct Hit {
     // Only image textures read uv; uv_id/uv_face/uv_t remember that earlier hit.
     int32_t uv_id, uv_face;
     float uv_t;
+    int32_t sig_code;  // signature walk only: 8 * world entry + face of the winner (row of SceneView::sig_faces)
 };
 
 // AABB::hit (include/ptAABB.h:30-48)
@@ -1043,6 +1048,7 @@ __device__ __forceinline__ bool world_hit_sig(const SceneView& sv, const Ray& r,
     h.t = closest;
     h.id = __float_as_int(sv.sig[SIG_SLOT * (code >> 3) + SIG_SLOT - 1]);
     h.face = code & 7;
+    h.sig_code = code;
     return true;
 }
 template <class W> struct is_any_world { static constexpr bool value = false; };
@@ -1068,7 +1074,7 @@ template <uint32_t F, class W = AnyWorld>
 __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, float tmin, float tmax, Hit& h, Pcg& g,
                                           int* lbvh_stack)
 {
-    h.id = PT_ID_MISS; h.face = 0; h.t = tmax; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
+    h.id = PT_ID_MISS; h.face = 0; h.t = tmax; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f; h.sig_code = -1;
     if constexpr (!is_any_world<W>::value) {
         return world_hit_sig<F, is_branchless<W>::value>(sv, r, tmin, tmax, h, W{});
     }
@@ -1234,6 +1240,44 @@ __device__ __forceinline__ void stale_uv(const SceneView& sv, const Ray& ray, co
     leaf_uv<F>(sv, us, ur, h.uv_t, h.uv_face, u, v);
 }
 
+// Normal of a rectangle or of face `face` of a box in the shape's own frame (src/ptRectangle.cu:25,79,133,
+// include/ptRectangle.h:199-212: the odd faces of a box sit under FlipNormals).
+PT_FN V3 flat_normal_local(int type, int face)
+{
+    if (type == PT_SHAPE_RECT_XY) return mk(0, 0, 1);
+    if (type == PT_SHAPE_RECT_XZ) return mk(0, 1, 0);
+    if (type == PT_SHAPE_RECT_YZ) return mk(1, 0, 0);
+    V3 n = (face < 2) ? mk(0, 0, 1) : (face < 4) ? mk(0, 1, 0) : mk(1, 0, 0);
+    if (face & 1) n = -n;
+    return n;
+}
+// RotateY::hit's rotation of the normal back to the world (include/ptRectangle.h:385-389); Translate leaves it alone.
+PT_FN V3 rotate_y_to_world(V3 n, float sinT, float cosT)
+{
+    return mk(cosT * n.x + sinT * n.z, n.y, -sinT * n.x + cosT * n.z);
+}
+
+// ---- finished surfaces of a signature world ------------------------------------------------------------
+// A signature world (Cornell box) has a handful of faces, each with one normal, one orthonormal
+// basis and, when every texture is a constant, one colour.  They are worked out once on the host, by
+// the functions above (the kernels' own arithmetic: IEEE operations in the same order, so the same
+// bits), one SIG_FACE-float row per (entry, face): normal, basis u, v, w, colour (albedo or emission),
+// material kind.  shade_sig reads the winner's row instead of chasing shape -> material -> texture
+// and rebuilding the basis (a square root and six divisions) at every bounce.
+constexpr int SIG_FACE = 16;
+struct SigFace { V3 n; Onb uvw; V3 colour; int32_t material_type; };
+PT_FN SigFace sig_face_make(int shape_type, int face, bool flip, bool rotated, float sinT, float cosT)
+{
+    SigFace f;
+    f.n = flat_normal_local(shape_type, face);
+    if (rotated) f.n = rotate_y_to_world(f.n, sinT, cosT);
+    if (flip) f.n = -f.n;
+    f.uvw = onb_from_w(f.n);
+    f.colour = mk(0, 0, 0);
+    f.material_type = 0;
+    return f;
+}
+
 template <uint32_t F>
 __device__ __forceinline__ Surface complete_hit(const SceneView& sv, const Ray& ray, const Hit& h)
 {
@@ -1258,13 +1302,10 @@ __device__ __forceinline__ Surface complete_hit(const SceneView& sv, const Ray& 
         sf.n = (sf.p - mk(s->p[0], s->p[1], s->p[2])) / s->p[3];
     } else if ((F & F_MSPHERE) && type == PT_SHAPE_MOVING_SPHERE) {
         sf.n = (sf.p - msphere_center(s->p, r.time)) / s->p[8];
-    } else if ((F & F_RECT) && type == PT_SHAPE_RECT_XY) { sf.n = mk(0, 0, 1); }
-    else if ((F & F_RECT) && type == PT_SHAPE_RECT_XZ) { sf.n = mk(0, 1, 0); }
-    else if ((F & F_RECT) && type == PT_SHAPE_RECT_YZ) { sf.n = mk(1, 0, 0); }
-    else if ((F & F_BOX) && type == PT_SHAPE_BOX) {
-        const int f = h.face;
-        sf.n = (f < 2) ? mk(0, 0, 1) : (f < 4) ? mk(0, 1, 0) : mk(1, 0, 0);
-        if (f & 1) sf.n = -sf.n;                                   // the odd faces sit under FlipNormals
+    } else if ((F & F_RECT) && (type == PT_SHAPE_RECT_XY || type == PT_SHAPE_RECT_XZ || type == PT_SHAPE_RECT_YZ)) {
+        sf.n = flat_normal_local(type, 0);
+    } else if ((F & F_BOX) && type == PT_SHAPE_BOX) {
+        sf.n = flat_normal_local(type, h.face);
     } else if ((F & F_TRIANGLE) && type == PT_SHAPE_TRIANGLE) {    // src/ptTriangle.cu:68-76
         const float* q = s->p;
         V3 v0 = mk(q[0], q[1], q[2]), v1 = mk(q[3], q[4], q[5]), v2 = mk(q[6], q[7], q[8]);
@@ -1584,6 +1625,58 @@ __device__ __forceinline__ bool shade(const SceneView& sv, Ray& ray, const Hit& 
     const V3 emitted = mk(0, 0, 0);
     thr = thr * (emitted + (atten * spdf) / pdf_value);
     ray.o = sf.p; ray.d = dir;           // time is kept (src/ptMain.cu:123,130)
+    return true;
+}
+
+// shade() for a signature world whose surfaces are tabulated (SceneView::sig_faces): Lambertian and
+// DiffuseLight materials over constant textures, one bare XZ rectangle as the light shape.  The
+// same arithmetic as shade() from the point where normal, basis and colour are known.
+template <uint32_t F, class W>
+__device__ __forceinline__ bool shade_sig(const SceneView& sv, Ray& ray, const Hit& h, V3& thr, Pcg& g)
+{
+    const float4* row = reinterpret_cast<const float4*>(sv.sig_faces + SIG_FACE * h.sig_code);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+    const V3 n = mk(r0.x, r0.y, r0.z);
+    Onb uvw;
+    uvw.u = mk(r0.w, r1.x, r1.y); uvw.v = mk(r1.z, r1.w, r2.x); uvw.w = mk(r2.y, r2.z, r2.w);
+    const V3 colour = mk(r3.x, r3.y, r3.z);
+    const int material_type = __float_as_int(r3.w);
+    // the hit point: ray.pointAt(t) in the shape's own frame, carried back out (complete_hit)
+    V3 p;
+    const float* q = sv.sig + SIG_SLOT * (h.sig_code >> 3);
+    if (__float_as_int(q[SIG_SLOT - 2]) != 0) {                   // Translate(RotateY(Box)): to_local, pointAt, to_world
+        const float sinT = q[9], cosT = q[10];
+        V3 o = ray.o - mk(q[6], q[7], q[8]);
+        const float ox = cosT * o.x - sinT * o.z, oz = sinT * o.x + cosT * o.z;
+        const float dx = cosT * ray.d.x - sinT * ray.d.z, dz = sinT * ray.d.x + cosT * ray.d.z;
+        const V3 pl = mk(ox, o.y, oz) + h.t * mk(dx, ray.d.y, dz);
+        p = mk(cosT * pl.x + sinT * pl.z, pl.y, -sinT * pl.x + cosT * pl.z) + mk(q[6], q[7], q[8]);
+    } else {
+        p = at(ray, h.t);
+    }
+    if (material_type == PT_MAT_DIFFUSE_LIGHT) {                    // include/ptMaterial.h:262-272
+        V3 emitted = mk(0, 0, 0);
+        if (dot(n, ray.d) < 0) emitted = colour;
+        thr = thr * emitted;
+        return false;
+    }
+    V3 dir;
+    const bool pick_light = g.rand() < 0.5f;                        // MixturePdf::generate, include/ptPDF.h:94-100 (see shade)
+    const float d1 = g.rand();
+    const float d2 = g.rand();
+    if (pick_light) {                                               // include/ptRectangle.h:91-95
+        const PtShape* ls = &sv.shapes[sv.lights[0]];
+        V3 rp = mk(ls->p[0] + d2 * (ls->p[1] - ls->p[0]), ls->p[4], ls->p[2] + d1 * (ls->p[3] - ls->p[2]));
+        dir = rp - p;
+    } else {
+        dir = onb_local(uvw, random_cosine_direction(d1, d2));
+    }
+    const float pdf_value = 0.5f * lights_pdf<F>(sv, p, dir) + 0.5f * cosine_pdf_value(uvw, dir);
+    const float cosine = dot(n, unit(dir));
+    const float spdf = (cosine < 0) ? 0.0f : cosine / PI_F;
+    const V3 emitted = mk(0, 0, 0);
+    thr = thr * (emitted + (colour * spdf) / pdf_value);
+    ray.o = p; ray.d = dir;           // time is kept (src/ptMain.cu:123,130)
     return true;
 }
 

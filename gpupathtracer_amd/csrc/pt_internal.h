@@ -48,10 +48,19 @@ constexpr uint32_t M_SPHERES_LBVH = M_SPHERES | F_LBVH;
 constexpr uint32_t M_TRIMESH = F_RECT | F_TRIANGLE | F_LIGHTS | F_LBVH;
 constexpr uint32_t M_ALL = F_ALL & ~F_LBVH;
 constexpr uint32_t M_ALL_LBVH = F_ALL;
+// The RTNW final scene's kinds (src/ptMain.cu:350-421): spheres, boxes in a reference BVH, a rectangle lamp,
+// two media, metal / glass / smoke, marble noise and the image texture -- no wrappers, triangles, checkers, sky
+// or light shapes beyond the one rectangle, whose code costs the all-features kernels registers and scratch.
+constexpr uint32_t M_FINAL = F_SPHERE | F_MSPHERE | F_RECT | F_BOX | F_MEDIUM | F_REFBVH | F_LIGHTS | F_METAL | F_DIELECTRIC |
+                             F_ISOTROPIC | F_NOISE | F_IMAGE;
+constexpr uint32_t M_FINAL_LBVH = M_FINAL | F_LBVH;
 
-constexpr int N_VARIANTS = 8;
-constexpr int V_CORNELL_WORLD_FLAT = 7;   // the same walk without control flow (launches that leave few waves per SIMD)
-constexpr int V_CORNELL_WORLD = 6;    // M_CORNELL with the CornellWorld signature walk (the fused kernels and the closest-hit kernel)
+enum : int {
+    V_CORNELL = 0, V_SPHERES = 1, V_SPHERES_LBVH = 2, V_TRIMESH = 3, V_ALL = 4, V_ALL_LBVH = 5,
+    V_CORNELL_WORLD = 6,        // M_CORNELL with the CornellWorld signature walk (the fused kernels and the closest-hit kernel)
+    V_CORNELL_WORLD_FLAT = 7,   // the same walk without control flow (launches that leave few waves per SIMD)
+    V_FINAL = 8, V_FINAL_LBVH = 9, N_VARIANTS = 10
+};
 }  // namespace ptk
 
 struct PtScene {
@@ -71,6 +80,20 @@ struct PtScene {
     PtRenderStats last{};
 };
 
+
+// Every (feature mask, world walk) the fused kernels are compiled for: X is `template struct` in the
+// translation unit that compiles one of them, `extern template struct` where they are only launched.
+#define PT_KERNEL_VARIANTS(X)                                        \
+    X FusedLaunch<ptk::M_CORNELL, ptd::AnyWorld>;                    \
+    X FusedLaunch<ptk::M_SPHERES, ptd::AnyWorld>;                    \
+    X FusedLaunch<ptk::M_SPHERES_LBVH, ptd::AnyWorld>;               \
+    X FusedLaunch<ptk::M_TRIMESH, ptd::AnyWorld>;                    \
+    X FusedLaunch<ptk::M_ALL, ptd::AnyWorld>;                        \
+    X FusedLaunch<ptk::M_ALL_LBVH, ptd::AnyWorld>;                   \
+    X FusedLaunch<ptk::M_CORNELL, ptd::CornellWorld>;                \
+    X FusedLaunch<ptk::M_CORNELL, ptd::Branchless<ptd::CornellWorld>>; \
+    X FusedLaunch<ptk::M_FINAL, ptd::AnyWorld>;                      \
+    X FusedLaunch<ptk::M_FINAL_LBVH, ptd::AnyWorld>;
 
 namespace pt {
 // Staged (wavefront) scheduler, pt_wavefront.hip.  Blocks until the frame is complete.

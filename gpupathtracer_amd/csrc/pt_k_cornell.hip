@@ -1,0 +1,6 @@
+// Compiles the fused radiance kernels and the closest-hit kernel of these specialisations (pt_kernels.h).
+#include "pt_kernels.h"
+
+template struct FusedLaunch<ptk::M_CORNELL, ptd::AnyWorld>;
+template struct FusedLaunch<ptk::M_CORNELL, ptd::CornellWorld>;
+template struct FusedLaunch<ptk::M_CORNELL, ptd::Branchless<ptd::CornellWorld>>;

@@ -291,11 +291,11 @@ void launch_round_variant(int variant, const SceneView& sv, const RenderArgs& ra
 {
     using namespace ptk;
     switch (variant) {
-    case 0: case V_CORNELL_WORLD: launch_round<M_CORNELL>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case 1: launch_round<M_SPHERES>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case 2: launch_round<M_SPHERES_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case 3: launch_round<M_TRIMESH>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case 4: launch_round<M_ALL>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_CORNELL: case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_round<M_CORNELL>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_SPHERES: launch_round<M_SPHERES>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_SPHERES_LBVH: launch_round<M_SPHERES_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_TRIMESH: launch_round<M_TRIMESH>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_ALL: case V_FINAL: launch_round<M_ALL>(sv, ra, w, parity, nq, blocks, out, st); break;
     default: launch_round<M_ALL_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
     }
 }
