@@ -17,7 +17,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptcore.so")
+    """The in-tree build; PT_LIBPTCORE_PATH names another build of the same library (kernel experiments)."""
+    return os.environ.get("PT_LIBPTCORE_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptcore.so")
 
 
 class PtError(RuntimeError):

@@ -25,6 +25,9 @@ using namespace ptk;
 // sphere scene in the LBVH 16.9 -> 13.0 ms at 6 (3: 16.9, 4: 14.5, 5: 13.5).
 __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 {
+#ifdef PT_EXP_CORNELL_BLOCKS
+    if (F == M_CORNELL) return PT_EXP_CORNELL_BLOCKS;
+#endif
     return (F & F_REFBVH) ? 4 : (F == M_CORNELL) ? 6 : (F == M_SPHERES_LBVH) ? 6 : (F == M_TRIMESH) ? 6 : 1;
 }
 

@@ -129,3 +129,175 @@ def test_survey_image_hashes(oracle, key, name, aspect, nx, ny, ns):
     """Not a gate: shows up as XPASS the day a convention (or a fix of the oracle) reproduces a hash."""
     img = oracle.render(pt.builtin_scene(name, aspect), nx, ny, ns)
     assert "%016x" % oracle.fnv1a(img) == PINS["image_hashes_not_reproduced"][key]
+
+
+# ---- argument evaluation order of the reference's host compiler -------------------------------------------
+
+def _eval_order():
+    """Runs tests/evalorder/eval_order.cpp (shape-alikes of the reference's multi-draw expressions over
+    a counting generator) under g++, the reference's host compiler, and returns {label: {slot: value}}."""
+    import shutil
+    import subprocess
+    import tempfile
+    src = os.path.join(HERE, "evalorder", "eval_order.cpp")
+    recorded = open(os.path.join(HERE, "evalorder", "eval_order_gxx.txt")).read()
+    if shutil.which("g++"):
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = os.path.join(tmp, "eval_order")
+            subprocess.check_call(["g++", "-O2", "-std=c++11", src, "-o", exe])
+            out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout
+        assert out == recorded, "g++ here orders the draws differently from the recorded run"
+    res = {}
+    for line in recorded.splitlines():
+        label, *tokens = line.split()
+        vals, cur = {}, None
+        for tok in tokens:                                    # "slot=value" opens a slot, a bare number adds to it
+            if "=" in tok:
+                cur, v = tok.split("=")
+                vals[cur] = [float(v)]
+            else:
+                vals[cur].append(float(tok))
+        res[label] = vals
+    return res
+
+
+def test_scene_builders_draw_in_the_order_gxx_evaluates(oracle):
+    """random_scene (src/ptMain.cu:246-283) rebuilt here from the SimpleRng stream with the draw order
+    the evaluation-order program reports for g++ -- z before x for the centre, the second centre before
+    the colour, colour and albedo components z, y, x -- must equal the library's scene in every float."""
+    order = _eval_order()
+    assert order["center"] == {"x": [2.0], "z": [1.0]}
+    assert order["moving_sphere"] == {"center1.y": [1.0], "colour": [67.0, 45.0, 23.0]}
+    assert order["metal"] == {"albedo": [3.0, 2.0, 1.0]}
+    assert order["cluster_sphere"] == {"centre": [3.0, 2.0, 1.0]}
+    assert order["xz_rectangle_random"] == {"x": [2.0], "z": [1.0]}
+    f = np.float32
+    stream = iter(oracle.simple_rng_stream(42, 13, 20000))
+    rand = lambda: f(next(stream))
+    desc = pt.builtin_scene("random", 2.0)
+    d = desc.c
+    k = 1                                                         # world[0] is the ground
+    for a in range(-11, 11):
+        for b in range(-11, 11):
+            choose = float(rand())
+            rz = float(rand()); rx = float(rand())                # z is drawn first
+            centre = (f(a + 0.9 * rx), f(0.2), f(b + 0.9 * rz))
+            diff = (f(centre[0] - f(4)), f(centre[1] - f(0.2)), f(centre[2] - f(0)))
+            length = np.sqrt(f(f(f(diff[0] * diff[0]) + f(diff[1] * diff[1])) + f(diff[2] * diff[2])))
+            if not float(length) > 0.9:
+                continue
+            s = d.shapes[d.world[k].index]
+            m = d.materials[s.material]
+            k += 1
+            assert (f(s.p[0]), f(s.p[1]), f(s.p[2])) == centre
+            if choose < 0.8:
+                c1y = f(centre[1] + f(0.5 * float(rand())))       # the second centre's draw comes before the colour's
+                cz = f(rand() * rand()); cy = f(rand() * rand()); cx = f(rand() * rand())
+                assert s.type == abi.SHAPE_MOVING_SPHERE and f(s.p[4]) == c1y and f(s.p[3]) == centre[0] and f(s.p[5]) == centre[2]
+                t = d.textures[m.texture]
+                assert m.type == abi.MAT_LAMBERTIAN and (f(t.color[0]), f(t.color[1]), f(t.color[2])) == (cx, cy, cz)
+            elif choose < 0.95:
+                mz = f(0.5 * float(rand())); my = f(0.5 * (1 + float(rand()))); mx = f(0.5 * (1 + float(rand())))
+                assert s.type == abi.SHAPE_SPHERE and m.type == abi.MAT_METAL
+                assert (f(m.albedo[0]), f(m.albedo[1]), f(m.albedo[2])) == (mx, my, mz)
+            else:
+                assert m.type == abi.MAT_DIELECTRIC
+    assert k == d.n_world - 3                                     # the three large spheres close the list
+
+
+def test_triangle_reports_the_unnormalised_t(oracle):
+    """Known answer the survey of the reference recorded for Triangle::hit (src/ptTriangle.cu:64-72):
+    a triangle whose determinant is 100, hit at true distance 5, reports rec.t = 500 while rec.p is
+    the true point (it comes from the barycentrics)."""
+    from gpupathtracer_amd import _abi as A
+    from gpupathtracer_amd.api import RAY_DTYPE
+    from tests._desc_tools import OwnedDesc
+    g = OwnedDesc(pt.builtin_scene("trimesh", 1.0))
+    tri = next(s for s in g.lists["shapes"] if s.type == abi.SHAPE_TRIANGLE)
+    s = A.PtShape(type=abi.SHAPE_TRIANGLE, flags=0, material=tri.material, xform_first=0, xform_count=0, tri_uv=-1)
+    for i, v in enumerate([0, 0, 0, 10, 0, 0, 0, 10, 0]):
+        s.p[i] = float(v)
+    g.lists["shapes"] = [s]
+    g.lists["world"] = [A.PtObject(type=abi.OBJ_SHAPE, index=0)]
+    g.lists["lights"] = []
+    g.finalize()
+    rays = np.zeros(1, RAY_DTYPE)
+    rays["o"][0] = (1, 1, 5)
+    rays["d"][0] = (0, 0, -1)
+    ids, rec = oracle.trace_records(g, rays)
+    assert ids[0] == 0 and rec[0, 0] == 500.0
+    np.testing.assert_allclose(rec[0, 1:4], np.array([1, 1, 0], np.float32), rtol=0, atol=1e-6)      # 0.1f * 10 is one ulp above 1
+
+
+def test_reference_bvh_of_the_final_scene_against_a_second_restatement(oracle):
+    """The tree final() builds over its 400 boxes (BVH::BVH, src/ptBVH.cu:15-43; quickSort and its Lomuto
+    partition with the last element as pivot and a strict '<' on bounds(0,0).min()[axis],
+    src/ptQuickSort.cu:19-81; one SimpleRng draw per node for the axis), built a second time here,
+    independently of the library's host code, and compared node for node: structure, leaf order, boxes."""
+    f = np.float32
+    desc = pt.builtin_scene("final", 16 / 9)
+    d = desc.c
+    boxes = [i for i in range(d.n_shapes) if d.shapes[i].type == abi.SHAPE_BOX]
+    assert boxes == list(range(400))
+    stream = iter(oracle.simple_rng_stream(42, 13, 400 + 2000))
+    # the heights consumed one draw each (src/ptMain.cu:369-380): y1 = 100 * (rand + 0.01f)
+    for i in boxes:
+        y1 = f(f(100) * f(f(next(stream)) + f(0.01)))
+        assert f(d.shapes[i].p[4]) == y1 and d.shapes[i].p[1] == 0.0
+    lo = {i: np.array(d.shapes[i].p[0:3], f) for i in boxes}      # Box::bounds = (pmin, pmax), include/ptRectangle.h:219-223
+    hi = {i: np.array(d.shapes[i].p[3:6], f) for i in boxes}
+
+    def partition(lst, l, h, axis):
+        x = lst[h]
+        i = l - 1
+        for j in range(l, h):
+            if lo[lst[j]][axis] < lo[x][axis]:
+                i += 1
+                lst[i], lst[j] = lst[j], lst[i]
+        lst[i + 1], lst[h] = lst[h], lst[i + 1]
+        return i + 1
+
+    def quick_sort(lst, axis):
+        stack = [(0, len(lst) - 1)]
+        while stack:
+            l, h = stack.pop()
+            p = partition(lst, l, h, axis)
+            pushes = []
+            if p - 1 > l:
+                pushes.append((l, p - 1))
+            if p + 1 < h:
+                pushes.append((p + 1, h))
+            stack.extend(pushes)                                  # the right part is pushed last and popped first, as there
+
+    def build(lst):
+        axis = int(f(3) * f(next(stream)))
+        quick_sort(lst, axis)
+        n = len(lst)
+        if n == 1:
+            left = right = ("leaf", lst[0])
+        elif n == 2:
+            left, right = ("leaf", lst[0]), ("leaf", lst[1])
+        else:
+            half = n // 2
+            a, b = lst[:half], lst[half:]
+            left = build(a)
+            right = build(b)
+            lst[:half], lst[half:] = a, b
+        bl = lambda c: (lo[c[1]], hi[c[1]]) if c[0] == "leaf" else (c[3], c[4])
+        (llo, lhi), (rlo, rhi) = bl(left), bl(right)
+        return ("node", left, right, np.fmin(llo, rlo), np.fmax(lhi, rhi))
+
+    mine = build(list(boxes))
+    assert d.n_bvhs == 1
+
+    def same(node, link):
+        if node[0] == "leaf":
+            assert link < 0 and ~link == node[1]
+            return 1
+        assert link >= 0
+        nd = d.bvh_nodes[link]
+        np.testing.assert_array_equal(np.array(nd.bmin[:], f).view(np.uint32), node[3].view(np.uint32))
+        np.testing.assert_array_equal(np.array(nd.bmax[:], f).view(np.uint32), node[4].view(np.uint32))
+        return same(node[1], nd.left) + same(node[2], nd.right)
+
+    assert same(mine, d.bvhs[0].root) >= 400
