@@ -14,6 +14,14 @@ import gpupathtracer_amd as pt                     # noqa: E402
 from gpupathtracer_amd import abi                  # noqa: E402
 
 
+def synthetic_earthmap():
+    """512x256 RGB8, the size of the reference's earthmap.jpg (the JPEG itself does not travel and
+    is not decoded here): a fixed arithmetic pattern, the same as `ptrace --earthmap synthetic`."""
+    import numpy as np
+    j, i = np.mgrid[0:256, 0:512]
+    return np.stack([(i * 7 + j * 13) & 255, (i ^ (j * 3)) & 255, ((i * j) >> 3) & 255], -1).astype(np.uint8)
+
+
 def run(label, desc, nx, ny, spp, steps=2, **kw):
     t0 = time.perf_counter()
     sc = pt.Scene(desc)
@@ -52,10 +60,14 @@ def main():
     if a.only in ("", "c1list"):
         res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1, **kw))
     if a.only in ("", "c3"):
-        res.append(run("C3 final 1920x1080", pt.builtin_scene("final", 16 / 9), 1920, 1080, 256 // q, **kw))
+        res.append(run("C3 final 1920x1080, synthetic 512x256 earth map, reference BVH walked as is",
+                       pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap()), 1920, 1080, 256 // q, **kw))
     if a.only in ("", "c3lbvh"):
-        res.append(run("C3 final 1920x1080, boxes of the reference BVH in the library's LBVH", pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH),
-                       1920, 1080, 256 // q, **kw))
+        res.append(run("C3 final 1920x1080, synthetic 512x256 earth map, boxes of the reference BVH in the library's LBVH",
+                       pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap(), accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, **kw))
+    if a.only in ("", "c3noearth"):
+        res.append(run("C3 final 1920x1080 without the earth sphere (the reference's device branch), LBVH",
+                       pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, **kw))
     if a.only in ("", "c4"):
         d = pt.trimesh_scene(a.grid, 16 / 9)
         d.c.accel = abi.ACCEL_LBVH

@@ -6,11 +6,14 @@
 // reference lacks (its scene is a source edit at src/ptMain.cu:559), and --stream-in / --stream-out,
 // which read and write the scene byte stream main() builds for its device (src/ptMain.cu:560-572),
 // and --pass-samples K, which renders in passes of K samples and reports progress after each
-// (the reference's Progress display, src/ptMain.cu:663-677, on the GPU path).  The reference parses with
+// (the reference's Progress display, src/ptMain.cu:663-677, on the GPU path), and --earthmap, the texels of
+// the final scene's earth sphere (the reference decodes earthmap.jpg with stb_image in its host branch,
+// src/ptMain.cu:396-402; here a binary PPM, or "synthetic" for a fixed 512x256 pattern).  The reference parses with
 // the vendored cxxopts; getopt_long gives the same short/long spellings here.
 #include <getopt.h>
 
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,13 +34,41 @@ int fail(const char* what)
     return EXIT_FAILURE;
 }
 
+// Texels for the final scene's earth sphere: a binary PPM (P6, maxval 255), or the word "synthetic" for a
+// fixed 512x256 pattern (the size of the reference's earthmap.jpg; not its content).
+bool load_earthmap(const std::string& arg, std::vector<uint8_t>* texels, int* w, int* h)
+{
+    if (arg == "synthetic") {
+        *w = 512; *h = 256;
+        texels->resize((size_t)3 * 512 * 256);
+        for (int j = 0; j < 256; j++)
+            for (int i = 0; i < 512; i++) {
+                uint8_t* t = &(*texels)[3 * ((size_t)j * 512 + i)];
+                t[0] = (uint8_t)((i * 7 + j * 13) & 255); t[1] = (uint8_t)((i ^ (j * 3)) & 255); t[2] = (uint8_t)(((i * j) >> 3) & 255);
+            }
+        return true;
+    }
+    std::ifstream f(arg, std::ios::binary);
+    std::string magic;
+    int maxval = 0;
+    if (!f || !(f >> magic >> *w >> *h >> maxval) || magic != "P6" || maxval != 255 || *w <= 0 || *h <= 0 || (long)*w * *h > (1L << 26)) {
+        std::cerr << "--earthmap: " << arg << " is not a binary PPM (P6, maxval 255)" << std::endl;
+        return false;
+    }
+    f.get();                                     // the single whitespace byte after maxval
+    texels->resize((size_t)3 * *w * *h);
+    f.read(reinterpret_cast<char*>(texels->data()), (std::streamsize)texels->size());
+    if (f.gcount() != (std::streamsize)texels->size()) { std::cerr << "--earthmap: " << arg << " is truncated" << std::endl; return false; }
+    return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
     bool quick = false, cpu = false, median = false;
     int ns = 100, nx = 128 * 4, ny = 128 * 4, maxDepth = 25, gpus = 1, passSamples = 0;
-    std::string outFile = "outputImage.ppm", scene = "random", accel = "auto", pipeline = "fused", streamIn, streamOut;
+    std::string outFile = "outputImage.ppm", scene = "random", accel = "auto", pipeline = "fused", streamIn, streamOut, earthmap;
 
     static const option longopts[] = {
         { "quick", no_argument, nullptr, 'q' }, { "cpu", no_argument, nullptr, 'c' }, { "median", no_argument, nullptr, 'm' },
@@ -48,6 +79,7 @@ int main(int argc, char** argv)
         { "gpus", required_argument, nullptr, 1001 }, { "accel", required_argument, nullptr, 1002 },
         { "pipeline", required_argument, nullptr, 1003 }, { "stream-in", required_argument, nullptr, 1004 },
         { "stream-out", required_argument, nullptr, 1005 }, { "pass-samples", required_argument, nullptr, 1006 },
+        { "earthmap", required_argument, nullptr, 1007 },
         { nullptr, 0, nullptr, 0 } };
     int c;
     while ((c = getopt_long(argc, argv, "qcmw:h:n:t:d:s:f:", longopts, nullptr)) != -1) {
@@ -69,11 +101,13 @@ int main(int argc, char** argv)
         case 1004: streamIn = optarg; break;
         case 1005: streamOut = optarg; break;
         case 1006: passSamples = std::atoi(optarg); break;
+        case 1007: earthmap = optarg; break;
         default:
             std::cerr << "usage: ptrace [-q] [-w W] [-h H] [-n SPP] [-d DEPTH] [-f out.{ppm,hdr,png,tga,bmp}]\n"
                          "              [--scene simple_spheres|simple_light|random|cornell|cornell_spheres|final|trimesh]\n"
                          "              [--gpus N] [--accel auto|list|lbvh] [--pipeline fused|wavefront]\n"
-                         "              [--stream-in scene.bin] [--stream-out scene.bin] [--pass-samples K] [-m]" << std::endl;
+                         "              [--stream-in scene.bin] [--stream-out scene.bin] [--pass-samples K] [-m]\n"
+                         "              [--earthmap map.ppm|synthetic]   (scene final: texels of the earth sphere)" << std::endl;
             return EXIT_FAILURE;
         }
     }
@@ -88,7 +122,12 @@ int main(int argc, char** argv)
         if (!f) { std::cerr << "cannot open " << streamIn << std::endl; return EXIT_FAILURE; }
         const std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         if (pt_scene_desc_from_stream(blob.data(), blob.size(), 0, &desc) != PT_OK) return fail("scene stream");
-    } else if (pt_scene_desc_builtin(scene.c_str(), aspect, nullptr, 0, 0, &desc) != PT_OK) return fail("scene");
+    } else {
+        std::vector<uint8_t> texels;
+        int tw = 0, th = 0;
+        if (!earthmap.empty() && !load_earthmap(earthmap, &texels, &tw, &th)) return EXIT_FAILURE;
+        if (pt_scene_desc_builtin(scene.c_str(), aspect, texels.empty() ? nullptr : texels.data(), tw, th, &desc) != PT_OK) return fail("scene");
+    }
     if (!streamOut.empty()) {
         size_t size = 0;
         if (pt_scene_desc_to_stream(desc, nullptr, 0, &size, nullptr) != PT_OK) return fail("scene stream");

@@ -273,6 +273,26 @@ def test_cli_writes_every_image_format(tmp_path, oracle):
         np.testing.assert_array_equal(got, want8)
     r = subprocess.run([exe, "--scene", "cornell", "-c"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU path" in r.stderr
+    # the final scene with its earth sphere (src/ptMain.cu:396-402): texels from a PPM, and the built-in synthetic map
+    tex = np.random.default_rng(4).integers(0, 256, (24, 48, 3), dtype=np.uint8)
+    ppm = str(tmp_path / "map.ppm")
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n48 24\n255\n" + tex.tobytes())
+    sys_path_bench = os.path.join(os.path.dirname(HERE), "bench")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pt_bench_configs", os.path.join(sys_path_bench, "configs.py"))
+    configs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(configs)
+    for arg, texels in ((ppm, tex), ("synthetic", configs.synthetic_earthmap())):
+        de = pt.builtin_scene("final", 48 / 32, earth_rgb=texels, accel=abi.ACCEL_LBVH)      # the CLI picks the LBVH for worlds with a BVH
+        assert de.c.n_world == 10
+        want = np.clip((255.99 * oracle.render(de, 48, 32, 4).astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)
+        out = str(tmp_path / "final.png")
+        r = subprocess.run([exe, "--scene", "final", "--earthmap", arg, "-w", "48", "-h", "32", "-n", "4", "-f", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        np.testing.assert_array_equal(np.asarray(Image.open(out).convert("RGB")), want)
+    r = subprocess.run([exe, "--scene", "final", "--earthmap", str(tmp_path / "img.png"), "-q"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not a binary PPM" in r.stderr
     r = subprocess.run([exe, "--scene", "nope", "-q"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown scene" in r.stderr
 
