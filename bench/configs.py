@@ -22,7 +22,31 @@ def synthetic_earthmap():
     return np.stack([(i * 7 + j * 13) & 255, (i ^ (j * 3)) & 255, ((i * j) >> 3) & 255], -1).astype(np.uint8)
 
 
-def run(label, desc, nx, ny, spp, steps=2, **kw):
+PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # fp32 vector, one add/mul per lane per cycle, no FMA credit (as bench.py)
+PEAK_HBM_GBS = 8000.0
+
+
+def roofline(model_key, bound, paths_per_s):
+    """achieved = algorithmic work per path (bench/work_model.json, counted by the instrumented CPU checker; for
+    the *_lbvh entries through a replay of the very tree the GPU walks) x measured paths per second."""
+    path = os.path.join(ROOT, "bench", "work_model.json")
+    if model_key is None or not os.path.exists(path):
+        return None
+    m = json.load(open(path))["configs"].get(model_key)
+    if m is None:
+        return None
+    if bound == "hbm":
+        if "bytes_per_path" not in m:
+            return None
+        a = m["bytes_per_path"] * paths_per_s / 1e9
+        return {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS,
+                "bytes_per_path": m["bytes_per_path"], "model": model_key}
+    a = m["flop_per_path"] * paths_per_s / 1e12
+    return {"bound": "valu", "achieved": a, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_VALU_TFLOPS,
+            "flop_per_path": m["flop_per_path"], "model": model_key}
+
+
+def run(label, desc, nx, ny, spp, steps=2, model=None, bound="valu", **kw):
     t0 = time.perf_counter()
     sc = pt.Scene(desc)
     pt.synchronize()
@@ -39,7 +63,8 @@ def run(label, desc, nx, ny, spp, steps=2, **kw):
     k = min(ms)
     out = {"config": label, "nx": nx, "ny": ny, "spp": spp, "kernel_ms": k, "Mpaths_per_s": nx * ny * spp / k / 1e3,
            "scene_create_s": create_s, "lbvh_nodes": int(pt.library().pt_scene_lbvh_nodes(sc._h, None, 0)),
-           "schedule": st.schedule, "pipeline": st.pipeline, "launches": st.n_launches, "shapes": desc.c.n_shapes, "world": desc.c.n_world}
+           "schedule": st.schedule, "pipeline": st.pipeline, "launches": st.n_launches, "shapes": desc.c.n_shapes, "world": desc.c.n_world,
+           "roofline": roofline(model, bound, nx * ny * spp / (k * 1e-3))}
     print(json.dumps(out), flush=True)
     return out
 
@@ -56,22 +81,22 @@ def main():
     kw = {"pipeline": abi.PIPELINE_WAVEFRONT} if a.pipeline == "wavefront" else {}
     res = []
     if a.only in ("", "c1"):
-        res.append(run("C1 random_scene 1920x1080 LBVH", pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 1024 // q, **kw))
+        res.append(run("C1 random_scene 1920x1080 LBVH", pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 1024 // q, model="random_lbvh", **kw))
     if a.only in ("", "c1list"):
-        res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1, **kw))
+        res.append(run("C1 random_scene 1920x1080 flat list (reference order)", pt.builtin_scene("random", 16 / 9), 1920, 1080, 64 // q if q < 16 else 4, steps=1, model="random", **kw))
     if a.only in ("", "c3"):
         res.append(run("C3 final 1920x1080, synthetic 512x256 earth map, reference BVH walked as is",
-                       pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap()), 1920, 1080, 256 // q, **kw))
+                       pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap()), 1920, 1080, 256 // q, model="final", **kw))
     if a.only in ("", "c3lbvh"):
         res.append(run("C3 final 1920x1080, synthetic 512x256 earth map, boxes of the reference BVH in the library's LBVH",
-                       pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap(), accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, **kw))
+                       pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap(), accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, model="final_lbvh", **kw))
     if a.only in ("", "c3noearth"):
         res.append(run("C3 final 1920x1080 without the earth sphere (the reference's device branch), LBVH",
                        pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, **kw))
     if a.only in ("", "c4"):
         d = pt.trimesh_scene(a.grid, 16 / 9)
         d.c.accel = abi.ACCEL_LBVH
-        res.append(run("C4 height field %d triangles in the Cornell enclosure 3840x2160 LBVH" % (2 * a.grid * a.grid), d, 3840, 2160, 64 // q, steps=1, **kw))
+        res.append(run("C4 height field %d triangles in the Cornell enclosure 3840x2160 LBVH" % (2 * a.grid * a.grid), d, 3840, 2160, 64 // q, steps=1, model="trimesh_lbvh", bound="hbm", **kw))
     return res
 
 

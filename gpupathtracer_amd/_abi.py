@@ -9,7 +9,7 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = ra
 TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(1, 5)
 OBJ_SHAPE, OBJ_MEDIUM, OBJ_BVH = 1, 2, 3
 AMBIENT_NONE, AMBIENT_CONSTANT, AMBIENT_SKY = 0, 1, 2
-ACCEL_LIST, ACCEL_LBVH = 0, 1
+ACCEL_LIST, ACCEL_LBVH, ACCEL_LBVH_BINARY, ACCEL_LBVH_WIDE = 0, 1, 2, 3
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL, SCHEDULE_WALK = 0, 1, 2, 3
 STREAM_KEEP_AMBIENT_COLOR = 1

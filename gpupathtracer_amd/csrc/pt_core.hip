@@ -31,12 +31,13 @@ namespace {
 // Specialisations in the order they are tried: a scene runs on the first whose mask covers it.
 const struct { int variant; uint32_t mask; } k_variants[] = {
     { V_CORNELL, M_CORNELL }, { V_SPHERES, M_SPHERES }, { V_SPHERES_LBVH, M_SPHERES_LBVH }, { V_TRIMESH, M_TRIMESH },
-    { V_FINAL, M_FINAL }, { V_FINAL_LBVH, M_FINAL_LBVH }, { V_ALL, M_ALL }, { V_ALL_LBVH, M_ALL_LBVH } };
+    { V_FINAL, M_FINAL }, { V_FINAL_LBVH, M_FINAL_LBVH }, { V_ALL, M_ALL }, { V_ALL_LBVH, M_ALL_LBVH },
+    { V_SPHERES_LBVH4, M_SPHERES_LBVH4 }, { V_TRIMESH4, M_TRIMESH4 }, { V_FINAL_LBVH4, M_FINAL_LBVH4 }, { V_ALL_LBVH4, M_ALL_LBVH4 } };
 
 int pick_variant(uint32_t scene_mask)
 {
     for (const auto& v : k_variants)
-        if ((scene_mask & ~v.mask) == 0 && ((v.mask ^ scene_mask) & F_LBVH) == 0) return v.variant;
+        if ((scene_mask & ~v.mask) == 0 && ((v.mask ^ scene_mask) & (F_LBVH | F_LBVH4)) == 0) return v.variant;
     return -1;
 }
 
@@ -52,7 +53,11 @@ int pick_variant(uint32_t scene_mask)
     case V_CORNELL_WORLD: LAUNCH(M_CORNELL, CornellWorld); break;      \
     case V_CORNELL_WORLD_FLAT: LAUNCH(M_CORNELL, Branchless<CornellWorld>); break; \
     case V_FINAL: LAUNCH(M_FINAL, AnyWorld); break;                    \
-    default: LAUNCH(M_FINAL_LBVH, AnyWorld); break;                    \
+    case V_FINAL_LBVH: LAUNCH(M_FINAL_LBVH, AnyWorld); break;          \
+    case V_SPHERES_LBVH4: LAUNCH(M_SPHERES_LBVH4, AnyWorld); break;    \
+    case V_TRIMESH4: LAUNCH(M_TRIMESH4, AnyWorld); break;              \
+    case V_FINAL_LBVH4: LAUNCH(M_FINAL_LBVH4, AnyWorld); break;        \
+    default: LAUNCH(M_ALL_LBVH4, AnyWorld); break;                     \
     }
 
 void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
@@ -460,29 +465,47 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         for (float q : desc->shapes[i].p) if (!(std::fabs(q) <= ptd::TREE_RAY_LIMIT)) tree_sized = false;
     for (int i = 0; i < desc->n_xforms && tree_sized; i++)
         for (float q : desc->xforms[i].v) if (!(std::fabs(q) <= ptd::TREE_RAY_LIMIT)) tree_sized = false;
-    if (desc->accel == PT_ACCEL_LBVH && desc->n_world >= 2 && tree_sized) {
+    v.lbvh4 = nullptr;
+    const bool want_tree = desc->accel == PT_ACCEL_LBVH || desc->accel == PT_ACCEL_LBVH_BINARY || desc->accel == PT_ACCEL_LBVH_WIDE;
+    if (want_tree && desc->n_world >= 2 && tree_sized) {
         void* d_nodes = nullptr;
-        int n_nodes = 0, root = 0, rc = PT_OK;
+        void* d_wide = nullptr;
+        // Which form the walk reads when the caller leaves it open (MI355X, one frame each; binary / 4-wide): spheres 46.9 / 67.6 ms,
+        // 2 M triangles 17.7 / 18.3 ms, RTNW final 19.2 / 18.6 ms -- four box tests per fetch cost the vector unit
+        // what they save in fetches, except on the final scene's short tree with expensive box leaves.
+        const bool auto_wide = (mask & (F_MEDIUM | F_REFBVH)) != 0;
+        void** want_wide = (desc->accel == PT_ACCEL_LBVH_WIDE || (desc->accel == PT_ACCEL_LBVH && auto_wide)) ? &d_wide : nullptr;
+        int n_nodes = 0, root = 0, rc = PT_OK, depth = 0;
         bool built = false;
         LbvhPlan plan;
         bool in_table_order = !(mask & (F_MEDIUM | F_REFBVH));     // shapes only, listed in the order of the shape table:
         for (int i = 1; i < desc->n_world && in_table_order; i++)     // then the shape index is the tie order
             in_table_order = desc->world[i].index > desc->world[i - 1].index;
         if (in_table_order) {
-            rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
+            rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root, want_wide, &depth);
             built = true;
         } else {
             if (lbvh_plan(desc, &plan)) {
                 rc = pt::lbvh_build_leaves(plan.leaves.data(), (int)plan.leaves.size(), desc->camera[21], desc->camera[22],
-                                           v.shapes, v.xforms, &d_nodes, &n_nodes, &root);
+                                           v.shapes, v.xforms, &d_nodes, &n_nodes, &root, want_wide, &depth);
                 if (rc == PT_OK && !(upload(sc, plan.order.data(), plan.order.size(), &v.lbvh_order, "upload leaf order") &&
                                      upload(sc, plan.group.data(), plan.group.size(), &v.lbvh_group, "upload leaf groups") &&
                                      upload(sc, plan.leaf_gate.data(), plan.leaf_gate.size(), &v.ref_leaf_gate, "upload leaf gates"))) {
-                    (void)hipFree(d_nodes); pt_scene_destroy(sc); return PT_ERR_HIP;
+                    (void)hipFree(d_nodes); if (d_wide) (void)hipFree(d_wide); pt_scene_destroy(sc); return PT_ERR_HIP;
                 }
                 v.lbvh_prefix = plan.prefix;
                 built = true;
             }
+        }
+        // The walks keep pending nodes on a per-lane stack of LBVH_STACK entries: one per level for the
+        // binary tree, up to three per level of the 4-wide one.  A tree too deep for that (many leaves
+        // with one centroid) is not used: the wide form first, then the tree altogether (list walk).
+        if (built && rc == PT_OK && d_wide && 3 * ((depth + 1) / 2) > ptd::LBVH_STACK) { (void)hipFree(d_wide); d_wide = nullptr; }
+        if (built && rc == PT_OK && depth > ptd::LBVH_STACK) {
+            (void)hipFree(d_nodes); d_nodes = nullptr;
+            if (d_wide) { (void)hipFree(d_wide); d_wide = nullptr; }
+            v.lbvh_order = nullptr; v.lbvh_group = nullptr; v.ref_leaf_gate = nullptr; v.lbvh_prefix = desc->n_world;
+            built = false;
         }
         if (built && rc == PT_OK) {
             // plane coordinates of the tree's un-wrapped rectangles and box faces, per axis (ray_may_enter_tree)
@@ -520,7 +543,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
             if (!(upload(sc, all.data(), all.size(), &v.tree_planes, "upload tree planes") &&
                   upload(sc, first.data(), first.size(), &v.tree_plane_first, "upload tree plane runs") &&
                   upload(sc, members.data(), members.size(), &v.tree_plane_members, "upload tree plane members"))) {
-                (void)hipFree(d_nodes); pt_scene_destroy(sc); return PT_ERR_HIP;
+                (void)hipFree(d_nodes); if (d_wide) (void)hipFree(d_wide); pt_scene_destroy(sc); return PT_ERR_HIP;
             }
         }
         if (built) {
@@ -531,6 +554,11 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
             v.lbvh_cull = (mask & F_TRIANGLE) ? 0 : 1;
             sc->lbvh_nodes = n_nodes;
             mask |= F_LBVH;
+            if (d_wide) {
+                sc->allocs.push_back(d_wide);
+                v.lbvh4 = static_cast<const ptd::LbvhNode4*>(d_wide);
+                mask |= F_LBVH4;
+            }
         }
     }
     sc->mask = mask;
@@ -581,6 +609,7 @@ extern "C" void pt_scene_destroy(PtScene* sc)
     if (!sc) return;
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->bad_resume_host) (void)hipHostFree(sc->bad_resume_host);
+    if (sc->wf_workspace) (void)hipFree(sc->wf_workspace);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);
     if (sc->ev_k1) (void)hipEventDestroy(sc->ev_k1);
@@ -668,7 +697,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // Measured (MI355X): spheres in the LBVH, 1920x1080: TILES 13.0 ms, REFILL 13.9, WALK 14.4 (shading,
     // not the search, is most of a bounce there); 2 M triangles in the LBVH, 3840x2160: TILES 31.2,
     // REFILL 28.2, WALK 18.3 with 48 waiting lanes (32: 21.7, 40: 19.2, 44: 18.5, 52: 18.7).
-    if (p->schedule == PT_SCHEDULE_AUTO && sc->variant == V_SPHERES_LBVH) ra.refill = 0;
+    if (p->schedule == PT_SCHEDULE_AUTO && (sc->variant == V_SPHERES_LBVH || sc->variant == V_SPHERES_LBVH4)) ra.refill = 0;
     if (p->schedule == PT_SCHEDULE_WALK ||
         (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & ptd::F_TRIANGLE) &&
          sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1)) ra.refill = 2;

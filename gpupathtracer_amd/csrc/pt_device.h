@@ -44,7 +44,8 @@ enum : uint32_t {
     F_NOISE      = 1u << 15,
     F_IMAGE      = 1u << 16,
     F_SKY        = 1u << 17,
-    F_ALL        = (1u << 18) - 1
+    F_ALL        = (1u << 18) - 1,
+    F_LBVH4      = 1u << 18    // with F_LBVH: the walk reads the tree's 4-wide form (not part of F_ALL: a way to walk, not a scene feature)
 };
 
 constexpr float PI_F = 3.141592654f;   // CUDART_PI_F
@@ -55,6 +56,16 @@ struct LbvhNode {
     float rmin[3], rmax[3];
     int32_t left, right;
     int32_t pad0, pad1;
+};
+
+// The same tree with every second level folded away: up to four children per node, boxes stored
+// by axis so that one child's six bounds sit in the same lane of six 16-byte loads.
+constexpr int32_t LBVH4_EMPTY = 0x7fffffff;
+struct LbvhNode4 {
+    float bmin[3][4];      // [axis][child]
+    float bmax[3][4];
+    int32_t link[4];       // >= 0 node, < 0 ~shape, LBVH4_EMPTY: no child
+    int32_t pad[4];
 };
 
 struct SceneView {
@@ -70,6 +81,7 @@ struct SceneView {
     const PtObject*   world;
     const int32_t*    lights;
     const LbvhNode*   lbvh;
+    const LbvhNode4*  lbvh4;    // the 4-wide form of the same tree (kernels compiled with F_LBVH4 walk this one), or nullptr
     const float*      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
     const float*      sig_faces;    // signature walk: SIG_FACE floats per (entry, face): the finished surface (see shade_sig); nullptr = none
     const int32_t*    lbvh_order;   // per shape: its place in the sequence of tests the in-order walk makes (nullptr: the shape index)
@@ -787,9 +799,70 @@ __device__ __forceinline__ void lbvh_begin(const SceneView& sv, const Ray& r, fl
 }
 // one node or one leaf per step: sphere and triangle leaves cost about what a node's two box
 // tests cost, and grouping them by phase (as the reference-tree walk does) measured slower here
+// One box of a 4-wide node against the ray: slab()'s arithmetic on bounds held in registers.
+__device__ __forceinline__ bool slab6(float x0, float y0, float z0, float x1, float y1, float z1, V3 o, V3 inv, float tmin, float tmax, float& tnear)
+{
+    float tx0 = (x0 - o.x) * inv.x, tx1 = (x1 - o.x) * inv.x;
+    float ty0 = (y0 - o.y) * inv.y, ty1 = (y1 - o.y) * inv.y;
+    float tz0 = (z0 - o.z) * inv.z, tz1 = (z1 - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    tnear = tn;
+    return tn * 0.9999990f <= tf * 1.0000010f;
+}
+__device__ __forceinline__ void lbvh_push(LbvhWalk& w, int link, int* stack, int* spill)
+{
+    if (w.sp < LBVH_LDS_STACK) stack[w.sp * 64] = link;
+    else if (w.sp < LBVH_STACK) spill[w.sp - LBVH_LDS_STACK] = link;
+    w.sp++;
+}
 template <uint32_t F>
 __device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, float tmin, float tmax, LbvhWalk& w, int* stack, int* spill)
 {
+    if constexpr ((F & F_LBVH4) != 0) {
+        if (w.cur >= 0) {
+            // one 128-byte node: four child boxes and four links.  The nearest child that the ray meets is
+            // walked next, the others wait on the stack (in no particular order: the winner of a search
+            // does not depend on the visiting order, see list_order_better; only pruning does, a little).
+            const float4* q = reinterpret_cast<const float4*>(&sv.lbvh4[w.cur]);
+            const float4 x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
+            const int4 lk = *reinterpret_cast<const int4*>(&q[6]);
+            const float lim = sv.lbvh_cull != 0 ? w.best : tmax;       // see the binary step below
+            const float from = sv.lbvh_cull != 0 ? tmin : 0.0f;
+            float t0, t1, t2, t3;
+            const bool h0 = slab6(x0.x, y0.x, z0.x, x1.x, y1.x, z1.x, r.o, w.inv, from, lim, t0);       // link 0 is never empty
+            const bool h1 = slab6(x0.y, y0.y, z0.y, x1.y, y1.y, z1.y, r.o, w.inv, from, lim, t1);       // nor is link 1
+            const bool h2 = lk.z != LBVH4_EMPTY && slab6(x0.z, y0.z, z0.z, x1.z, y1.z, z1.z, r.o, w.inv, from, lim, t2);
+            const bool h3 = lk.w != LBVH4_EMPTY && slab6(x0.w, y0.w, z0.w, x1.w, y1.w, z1.w, r.o, w.inv, from, lim, t3);
+            int next = LBVH4_EMPTY;
+            float tn = 0.0f;
+            if (h0) { next = lk.x; tn = t0; }
+            if (h1) {
+                if (next == LBVH4_EMPTY) { next = lk.y; tn = t1; }
+                else { const bool nearer = t1 < tn; lbvh_push(w, nearer ? next : lk.y, stack, spill); if (nearer) { next = lk.y; tn = t1; } }
+            }
+            if (h2) {
+                if (next == LBVH4_EMPTY) { next = lk.z; tn = t2; }
+                else { const bool nearer = t2 < tn; lbvh_push(w, nearer ? next : lk.z, stack, spill); if (nearer) { next = lk.z; tn = t2; } }
+            }
+            if (h3) {
+                if (next == LBVH4_EMPTY) { next = lk.w; tn = t3; }
+                else { const bool nearer = t3 < tn; lbvh_push(w, nearer ? next : lk.w, stack, spill); if (nearer) { next = lk.w; tn = t3; } }
+            }
+            if (next != LBVH4_EMPTY) { w.cur = next; return false; }
+        } else {
+            const int id = ~w.cur;
+            float t; int face;
+            if (leaf_t<F>(sv, id, r, tmin, tmax, t, face)) {
+                if (accepts_nan<F>::value && t != t) w.odd = true;
+                if (!w.any || list_order_better(sv, t, id, w.best, w.best_id)) { w.any = true; w.best = t; w.best_id = id; w.best_face = face; }
+            }
+        }
+        if (w.sp == 0) return true;
+        --w.sp;
+        w.cur = (w.sp < LBVH_LDS_STACK) ? stack[w.sp * 64] : spill[w.sp - LBVH_LDS_STACK];
+        return false;
+    }
     if (w.cur >= 0) {
         const LbvhNode* n = &sv.lbvh[w.cur];
         // With triangles in the tree neither end of [tmin, best] bounds the distance: the reference

@@ -54,12 +54,18 @@ constexpr uint32_t M_ALL_LBVH = F_ALL;
 constexpr uint32_t M_FINAL = F_SPHERE | F_MSPHERE | F_RECT | F_BOX | F_MEDIUM | F_REFBVH | F_LIGHTS | F_METAL | F_DIELECTRIC |
                              F_ISOTROPIC | F_NOISE | F_IMAGE;
 constexpr uint32_t M_FINAL_LBVH = M_FINAL | F_LBVH;
+// the tree scenes again, walked through the tree's 4-wide form
+constexpr uint32_t M_SPHERES_LBVH4 = M_SPHERES_LBVH | F_LBVH4;
+constexpr uint32_t M_TRIMESH4 = M_TRIMESH | F_LBVH4;
+constexpr uint32_t M_FINAL_LBVH4 = M_FINAL_LBVH | F_LBVH4;
+constexpr uint32_t M_ALL_LBVH4 = M_ALL_LBVH | F_LBVH4;
 
 enum : int {
     V_CORNELL = 0, V_SPHERES = 1, V_SPHERES_LBVH = 2, V_TRIMESH = 3, V_ALL = 4, V_ALL_LBVH = 5,
     V_CORNELL_WORLD = 6,        // M_CORNELL with the CornellWorld signature walk (the fused kernels and the closest-hit kernel)
     V_CORNELL_WORLD_FLAT = 7,   // the same walk without control flow (launches that leave few waves per SIMD)
-    V_FINAL = 8, V_FINAL_LBVH = 9, N_VARIANTS = 10
+    V_FINAL = 8, V_FINAL_LBVH = 9,
+    V_SPHERES_LBVH4 = 10, V_TRIMESH4 = 11, V_FINAL_LBVH4 = 12, V_ALL_LBVH4 = 13, N_VARIANTS = 14
 };
 }  // namespace ptk
 
@@ -74,6 +80,8 @@ struct PtScene {
     unsigned* next_slot = nullptr;      // device counter of the fused scheduler's pixel-slot pool
     int* bad_resume_host = nullptr;     // pinned host word a progressive pass raises when its accumulator is not at first_sample
     int* bad_resume_dev = nullptr;      // the same word as the device sees it
+    void* wf_workspace = nullptr;       // staged scheduler: lane records and queues, kept between calls
+    size_t wf_workspace_bytes = 0;
     // timing of the most recent render
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
     bool have_timing = false;
@@ -93,7 +101,11 @@ struct PtScene {
     X FusedLaunch<ptk::M_CORNELL, ptd::CornellWorld>;                \
     X FusedLaunch<ptk::M_CORNELL, ptd::Branchless<ptd::CornellWorld>>; \
     X FusedLaunch<ptk::M_FINAL, ptd::AnyWorld>;                      \
-    X FusedLaunch<ptk::M_FINAL_LBVH, ptd::AnyWorld>;
+    X FusedLaunch<ptk::M_FINAL_LBVH, ptd::AnyWorld>;                 \
+    X FusedLaunch<ptk::M_SPHERES_LBVH4, ptd::AnyWorld>;              \
+    X FusedLaunch<ptk::M_TRIMESH4, ptd::AnyWorld>;                   \
+    X FusedLaunch<ptk::M_FINAL_LBVH4, ptd::AnyWorld>;                \
+    X FusedLaunch<ptk::M_ALL_LBVH4, ptd::AnyWorld>;
 
 namespace pt {
 // Staged (wavefront) scheduler, pt_wavefront.hip.  Blocks until the frame is complete.

@@ -17,18 +17,20 @@ using namespace ptk;
 
 // ---- kernels ----------------------------------------------------------------------------------------
 
-// Workgroups per CU the fused kernels are compiled for (a register cap).  The compiler's free choice
-// leaves the rectangle-scene kernel at 5 waves per SIMD and the full-feature kernels at 2; the
-// values below measured fastest on MI355X: Cornell 1024^2 124.5 -> 118.9 ms at 6 (7: 122.2, 8: 125.6,
-// spills), final scene 54.4 -> 40.5 ms at 4 (3: 43.3, 6: 40.9), 2M-triangle field 40.7 -> 33.1 ms at 6
-// (the LDS traversal stack allows six workgroups per CU; 8 with a shorter stack measured the same),
-// sphere scene in the LBVH 16.9 -> 13.0 ms at 6 (3: 16.9, 4: 14.5, 5: 13.5).
+// Workgroups per CU the fused kernels are compiled for (a register cap).  Measured on MI355X: the
+// rectangle-scene kernel is bound by vector issue and takes the same time at 5, 6, 7 and 8 (37.5 ms per
+// 512 spp of the 1024^2 Cornell frame): 6 leaves it without spills.  The 2 M-triangle walk gains from
+// occupancy (40.7 -> 33.1 ms at 6, where the LDS traversal stack still fits), the sphere tree likewise
+// (16.9 -> 13.0 ms at 6 although 71 registers then spill).  The kernels that carry the reference's
+// BVH, media and every material (RTNW final) take the same time at 2, 3, 4 and 5 -- 19.1 ms per 16 spp
+// through the library's tree, 40.4 ms through the reference's -- so they get 2: 256 registers, no
+// vector register goes to scratch memory, and the launch's memory traffic is the frame and the scene.
 __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 {
-#ifdef PT_EXP_CORNELL_BLOCKS
-    if (F == M_CORNELL) return PT_EXP_CORNELL_BLOCKS;
+#ifdef PT_EXP_BLOCKS            // kernel experiments: -DPT_EXP_BLOCKS=n overrides the table below for the file being compiled
+    return PT_EXP_BLOCKS;
 #endif
-    return (F & F_REFBVH) ? 4 : (F == M_CORNELL) ? 6 : (F == M_SPHERES_LBVH) ? 6 : (F == M_TRIMESH) ? 6 : 1;
+    return (F & F_REFBVH) ? 2 : (F == M_CORNELL) ? 6 : (F == M_SPHERES_LBVH) ? 6 : (F == M_TRIMESH) ? 6 : 1;
 }
 
 // One lane's path tracer state: the pixel's random stream, its running sum and the path in flight.

@@ -224,6 +224,49 @@ __global__ void k_emit(const int* left, const int* right, const uint64_t* keys, 
     nodes[i] = nd;
 }
 
+// ---- 4-wide collapse ------------------------------------------------------------------------------------
+// Every second level of the binary tree is folded into the level above it: a node at even depth
+// keeps its slot and takes its grandchildren (or, where a child is a leaf, that leaf) as its up to
+// four children; nodes at odd depth disappear.  One 128-byte fetch then decides four descents,
+// which halves the chain of dependent node fetches of a walk.  Depth = number of parent links to
+// the root, found by following them (trees here are a few dozen levels deep).
+__global__ void k_depth(const int* parent, int n_internal, int* depth, int* max_depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    int d = 0;
+    for (int p = parent[i]; p >= 0; p = parent[p]) d++;
+    depth[i] = d;
+    atomicMax(max_depth, d);
+}
+
+__global__ void k_emit_wide(const int* left, const int* right, const int* depth, const uint64_t* keys, const Box* leaf_boxes,
+                            const Box* node_boxes, const PtObject* world, int n_internal, ptd::LbvhNode4* nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    ptd::LbvhNode4 nd;
+    for (int c = 0; c < 4; c++) {
+        for (int a = 0; a < 3; a++) { nd.bmin[a][c] = FLT_MAX; nd.bmax[a][c] = -FLT_MAX; }
+        nd.link[c] = ptd::LBVH4_EMPTY; nd.pad[c] = 0;
+    }
+    if (depth[i] & 1) { nodes[i] = nd; return; }              // folded into its parent: the slot stays unused
+    int kids[4], n = 0;
+    const int pair[2] = { left[i], right[i] };
+    for (int s = 0; s < 2; s++) {
+        const int c = pair[s];
+        if (c >= 0) { kids[n++] = left[c]; kids[n++] = right[c]; }
+        else kids[n++] = c;
+    }
+    for (int c = 0; c < n; c++) {
+        const int k = kids[c];
+        const Box b = (k >= 0) ? node_boxes[k] : leaf_boxes[(unsigned)keys[~k]];
+        for (int a = 0; a < 3; a++) { nd.bmin[a][c] = b.mn[a]; nd.bmax[a][c] = b.mx[a]; }
+        nd.link[c] = (k >= 0) ? k : ~world[(unsigned)keys[~k]].index;
+    }
+    nodes[i] = nd;
+}
+
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -244,7 +287,7 @@ int hip_fail(hipError_t e, const char* what)
 namespace pt {
 
 int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,
-               void** d_nodes_out, int* n_nodes_out, int* root_out)
+               void** d_nodes_out, int* n_nodes_out, int* root_out, void** d_wide_out, int* depth_out)
 {
     const int n = desc->n_world;
     *d_nodes_out = nullptr; *n_nodes_out = 0; *root_out = 0;
@@ -255,13 +298,16 @@ int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* 
             return PT_ERR_UNSUPPORTED;
         }
     }
-    return lbvh_build_leaves(desc->world, n, desc->camera[21], desc->camera[22], d_shapes, d_xforms, d_nodes_out, n_nodes_out, root_out);
+    return lbvh_build_leaves(desc->world, n, desc->camera[21], desc->camera[22], d_shapes, d_xforms, d_nodes_out, n_nodes_out, root_out,
+                             d_wide_out, depth_out);
 }
 
 int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, const PtShape* d_shapes, const PtXform* d_xforms,
-                      void** d_nodes_out, int* n_nodes_out, int* root_out)
+                      void** d_nodes_out, int* n_nodes_out, int* root_out, void** d_wide_out, int* depth_out)
 {
     *d_nodes_out = nullptr; *n_nodes_out = 0; *root_out = 0;
+    if (d_wide_out) *d_wide_out = nullptr;
+    if (depth_out) *depth_out = 0;
     if (n < 2) { set_error("lbvh_build: fewer than two shapes"); return PT_ERR_INVALID; }
     for (int i = 0; i < n; i++)
         if (leaves[i].type != PT_OBJ_SHAPE) { set_error("lbvh_build: a leaf that is not a shape"); return PT_ERR_UNSUPPORTED; }
@@ -315,7 +361,28 @@ int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, c
     if ((e = hipMalloc(&nodes, (size_t)n_int * sizeof(LbvhNode))) != hipSuccess) { set_error("lbvh_build: out of device memory"); return PT_ERR_OOM; }
     hipLaunchKernelGGL(k_emit, dim3(GI), dim3(B), 0, nullptr, left.as<int>(), right.as<int>(), src, boxes.as<Box>(), nboxes.as<Box>(),
                        world.as<PtObject>(), n_int, static_cast<LbvhNode*>(nodes));
-    if ((e = hipDeviceSynchronize()) != hipSuccess) { (void)hipFree(nodes); return hip_fail(e, "kernels"); }
+    // depth of the binary tree (the walks' stacks are sized against it) and, on request, the 4-wide form
+    DevBuf depth, max_depth;
+    if (!depth.alloc((size_t)n_int * 4) || !max_depth.alloc(4)) { (void)hipFree(nodes); set_error("lbvh_build: out of device memory"); return PT_ERR_OOM; }
+    if ((e = hipMemset(max_depth.p, 0, 4)) != hipSuccess) { (void)hipFree(nodes); return hip_fail(e, "memset depth"); }
+    hipLaunchKernelGGL(k_depth, dim3(GI), dim3(B), 0, nullptr, parent.as<int>(), n_int, depth.as<int>(), max_depth.as<int>());
+    int h_depth = 0;
+    if ((e = hipMemcpy(&h_depth, max_depth.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) { (void)hipFree(nodes); return hip_fail(e, "read depth"); }
+    if (depth_out) *depth_out = h_depth + 1;                  // levels of internal nodes
+    if (d_wide_out) {
+        void* wide = nullptr;
+        if ((e = hipMalloc(&wide, (size_t)n_int * sizeof(ptd::LbvhNode4))) != hipSuccess) {
+            (void)hipFree(nodes); set_error("lbvh_build: out of device memory"); return PT_ERR_OOM;
+        }
+        hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, nullptr, left.as<int>(), right.as<int>(), depth.as<int>(), src, boxes.as<Box>(),
+                           nboxes.as<Box>(), world.as<PtObject>(), n_int, static_cast<ptd::LbvhNode4*>(wide));
+        *d_wide_out = wide;
+    }
+    if ((e = hipDeviceSynchronize()) != hipSuccess) {
+        (void)hipFree(nodes);
+        if (d_wide_out && *d_wide_out) { (void)hipFree(*d_wide_out); *d_wide_out = nullptr; }
+        return hip_fail(e, "kernels");
+    }
     *d_nodes_out = nodes;
     *n_nodes_out = n_int;
     *root_out = 0;             // Karras' root is internal node 0

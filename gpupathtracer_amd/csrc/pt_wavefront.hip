@@ -293,17 +293,12 @@ void launch_round_variant(int variant, const SceneView& sv, const RenderArgs& ra
     switch (variant) {
     case V_CORNELL: case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_round<M_CORNELL>(sv, ra, w, parity, nq, blocks, out, st); break;
     case V_SPHERES: launch_round<M_SPHERES>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case V_SPHERES_LBVH: launch_round<M_SPHERES_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case V_TRIMESH: launch_round<M_TRIMESH>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: launch_round<M_SPHERES_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_TRIMESH: case V_TRIMESH4: launch_round<M_TRIMESH>(sv, ra, w, parity, nq, blocks, out, st); break;
     case V_ALL: case V_FINAL: launch_round<M_ALL>(sv, ra, w, parity, nq, blocks, out, st); break;
     default: launch_round<M_ALL_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
     }
 }
-
-struct Workspace {
-    void* base = nullptr;
-    ~Workspace() { if (base) (void)hipFree(base); }
-};
 
 }  // namespace
 
@@ -313,11 +308,15 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
 {
     const uint32_t n_slots = (uint32_t)ra.n_wave_tiles * 64u;
     if (n_slots == 0) return PT_OK;
-    // one allocation: the lane records, then the queues and counters
+    // one allocation: the lane records, then the queues and counters.  The scene keeps it between calls
+    // (a host that renders frame after frame pays for it once); it grows when a larger shard comes along.
     const size_t bytes = (size_t)n_slots * sizeof(LaneRec) + (size_t)n_slots * (2 + N_SHADE_Q) * 4 + 64 * 4;
-    Workspace ws;
-    if (!hip_ok2(hipMalloc(&ws.base, bytes), "hipMalloc(wavefront state)")) return PT_ERR_OOM;
-    char* p = static_cast<char*>(ws.base);
+    if (sc->wf_workspace_bytes < bytes) {
+        if (sc->wf_workspace) { (void)hipFree(sc->wf_workspace); sc->wf_workspace = nullptr; sc->wf_workspace_bytes = 0; }
+        if (!hip_ok2(hipMalloc(&sc->wf_workspace, bytes), "hipMalloc(wavefront state)")) return PT_ERR_OOM;
+        sc->wf_workspace_bytes = bytes;
+    }
+    char* p = static_cast<char*>(sc->wf_workspace);
     WfState w{};
     w.n = n_slots;
     auto take = [&](size_t nbytes) { char* r = p; p += nbytes; return r; };

@@ -78,7 +78,7 @@ enum PtAmbientType { PT_AMBIENT_NONE = 0, PT_AMBIENT_CONSTANT = 1, PT_AMBIENT_SK
 /* How the library may search the world list. */
 enum PtAccel {
     PT_ACCEL_LIST = 0,        /* walk the list in order, exactly as HitableList::hit does           */
-    PT_ACCEL_LBVH = 1         /* library-built Morton LBVH; same closest hit and the same winner on  */
+    PT_ACCEL_LBVH = 1,        /* library-built Morton LBVH; same closest hit and the same winner on  */
                               /* exact ties as the in-order walk.  A list of PT_OBJ_SHAPE entries    */
                               /* goes into the tree whole.  A list that starts with an un-wrapped    */
                               /* reference BVH (leaves of one tie kind) and/or shapes goes in up to  */
@@ -89,6 +89,11 @@ enum PtAccel {
                               /* the reference's rectangle, box and triangle tests accept a NaN t    */
                               /* (src/ptRectangle.cu:15: a ray lying in a rectangle's plane, a       */
                               /* non-finite ray) are answered the in-order way, never by the tree.   */
+                              /* The walk reads the tree in the form that measured faster for the    */
+                              /* scene's kinds; the two values below pick one explicitly.            */
+    PT_ACCEL_LBVH_BINARY = 2, /* PT_ACCEL_LBVH walked as built: 64-byte nodes, two child boxes each  */
+    PT_ACCEL_LBVH_WIDE = 3    /* PT_ACCEL_LBVH with every second level folded away: 128-byte nodes,  */
+                              /* four child boxes each, half the dependent node fetches per search   */
 };
 
 /* Which scheduler runs the radiance pipeline stages. */

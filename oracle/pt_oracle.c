@@ -43,9 +43,9 @@
 #ifdef PT_ORACLE_COUNT
 typedef struct {
     uint64_t flop, libm, iop, draws, paths, world_hits, rect_tests, sphere_tests, triangle_tests,
-             aabb_tests, diffuse_scatters, accepted_hits;
+             aabb_tests, diffuse_scatters, accepted_hits, tree_nodes, tree_leaves;
 } work_t;
-#define WORK_FIELDS 12
+#define WORK_FIELDS 14
 static __thread work_t W;
 static work_t W_total;
 #define FL(n) (W.flop += (n))
@@ -632,16 +632,112 @@ static int medium_hit(const PtSceneDesc* sc, int m, const ray_t* r, float t0, fl
     return 0;
 }
 
+#ifdef PT_ORACLE_COUNT
+/* ---- work of a search through the product's tree (counting build only) ---------------------------
+ * The product does not walk long lists entry by entry: it searches a binary tree it built over the
+ * list's leading run of shapes (64-byte nodes holding both children's boxes) and walks only the
+ * rest of the list in order.  To price THAT search, the tree is handed over here (copied back from
+ * the device by the caller) and every world_hit counts the work of a replay of it -- node visits,
+ * leaf tests with their arithmetic -- instead of the work of the flat walk.  The hit itself still
+ * comes from the flat walk unless the caller asks for the replay's own answer (a 2 M-entry list
+ * would take the flat walk seconds per ray); the counters, not the hit, are what this is for. */
+typedef struct { float lmin[3], lmax[3], rmin[3], rmax[3]; int32_t left, right, pad0, pad1; } tree_node;
+static const tree_node* T_nodes = NULL;
+static int T_root = 0, T_cull = 0, T_prefix = 0, T_trust = 0;
+void oracle_count_through_tree(const void* nodes64, int root, int cull, int prefix, int trust_replay)
+{
+    T_nodes = (const tree_node*)nodes64; T_root = root; T_cull = cull; T_prefix = prefix; T_trust = trust_replay;
+}
+static int tree_slab(const float* bmin, const float* bmax, v3 o, v3 inv, float tmin, float tmax, float* tnear)
+{
+    float tx0 = (bmin[0] - o.x) * inv.x, tx1 = (bmax[0] - o.x) * inv.x;
+    float ty0 = (bmin[1] - o.y) * inv.y, ty1 = (bmax[1] - o.y) * inv.y;
+    float tz0 = (bmin[2] - o.z) * inv.z, tz1 = (bmax[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    FL(27);                      /* 6 sub, 6 mul, 12 min/max, 2 mul, 1 compare */
+    *tnear = tn;
+    return tn * 0.9999990f <= tf * 1.0000010f;
+}
+static int shape_hit(const PtSceneDesc* sc, int shape, const ray_t* r, float tmin, float tmax, hitrec* rec, pcg_t* rng);
+static int inclusive_kind(int type) { return type != PT_SHAPE_SPHERE && type != PT_SHAPE_MOVING_SPHERE; }
+/* near child first, pruned by the best distance unless triangles are in the tree (their reported t is
+ * not a distance); a later list entry wins an exact tie iff it is of an inclusive kind */
+static int tree_replay(const PtSceneDesc* sc, const ray_t* r, float tmin, float tmax, hitrec* rec, pcg_t* rng)
+{
+    int stack[128], sp = 0, cur = T_root, any = 0;
+    float best = tmax;
+    v3 inv = V(1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z);
+    FL(3);
+    for (;;) {
+        if (cur >= 0) {
+            const tree_node* n = &T_nodes[cur];
+            float tl, tr;
+            const float lim = T_cull ? best : tmax, from = T_cull ? tmin : 0.0f;
+            EV(tree_nodes);
+            int hl = tree_slab(n->lmin, n->lmax, r->o, inv, from, lim, &tl);
+            int hr = tree_slab(n->rmin, n->rmax, r->o, inv, from, lim, &tr);
+            int cl = n->left, cr = n->right;
+            if (hl && hr) {
+                FL(1);
+                if (tr < tl) { int tmp = cl; cl = cr; cr = tmp; }
+                if (sp < 128) stack[sp++] = cr;
+                cur = cl;
+                continue;
+            }
+            if (hl) { cur = cl; continue; }
+            if (hr) { cur = cr; continue; }
+        } else {
+            hitrec temp;
+            memset(&temp, 0, sizeof temp);
+            EV(tree_leaves);
+            if (shape_hit(sc, ~cur, r, tmin, tmax, &temp, rng)) {
+                int better = !any || temp.t < best;
+                if (any && temp.t == best) better = (~cur > rec->prim) ? inclusive_kind(sc->shapes[~cur].type) : !inclusive_kind(sc->shapes[rec->prim].type);
+                FL(2);
+                if (better) { any = 1; best = temp.t; *rec = temp; }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return any;
+}
+#endif
+
 /* The top-level HitableList::hit (src/ptHitableList.cu:12-27). */
+static int world_hit_list(const PtSceneDesc* sc, const ray_t* r, float tmin, float tmax,
+                          hitrec* rec, pcg_t* rng, int first, int hit_anything, float closest);
 static int world_hit(const PtSceneDesc* sc, const ray_t* r, float tmin, float tmax,
                      hitrec* rec, pcg_t* rng)
 {
-    hitrec temp;
+#ifdef PT_ORACLE_COUNT
+    if (T_nodes) {
+        EV(world_hits);
+        /* the work: a replay of the tree over the list's leading run, then the rest of the list in order */
+        pcg_t count_rng = *rng;
+        hitrec replay;
+        memset(&replay, 0, sizeof replay);
+        int any = tree_replay(sc, r, tmin, tmax, &replay, &count_rng);
+        any = world_hit_list(sc, r, tmin, tmax, &replay, &count_rng, T_prefix, any, any ? replay.t : tmax);
+        if (T_trust) { *rng = count_rng; if (any) *rec = replay; return any; }
+        /* the answer: the flat walk, its own work left out of the count */
+        const work_t keep = W;
+        int h = world_hit_list(sc, r, tmin, tmax, rec, rng, 0, 0, tmax);
+        W = keep;
+        return h;
+    }
+#endif
     EV(world_hits);
+    return world_hit_list(sc, r, tmin, tmax, rec, rng, 0, 0, tmax);
+}
+static int world_hit_list(const PtSceneDesc* sc, const ray_t* r, float tmin, float tmax,
+                          hitrec* rec, pcg_t* rng, int first, int hit_anything, float closest)
+{
+    hitrec temp;
     memset(&temp, 0, sizeof temp);     /* the reference leaves temp_rec uninitialised */
-    int hit_anything = 0;
-    float closest = tmax;
-    for (int i = 0; i < sc->n_world; i++) {
+    (void)tmax;
+    for (int i = first; i < sc->n_world; i++) {
         const PtObject* ob = &sc->world[i];
         int h = 0;
         if (ob->type == PT_OBJ_SHAPE) h = shape_hit(sc, ob->index, r, tmin, closest, &temp, rng);

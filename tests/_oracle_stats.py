@@ -11,7 +11,7 @@ from gpupathtracer_amd import _abi as A
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELDS = ["flop", "libm", "iop", "draws", "paths", "world_hits", "rect_tests", "sphere_tests", "triangle_tests",
-          "aabb_tests", "diffuse_scatters", "accepted_hits"]
+          "aabb_tests", "diffuse_scatters", "accepted_hits", "tree_nodes", "tree_leaves"]
 _LIB = None
 
 
@@ -25,16 +25,28 @@ def _load():
         _LIB = C.CDLL(so)
         _LIB.oracle_render.argtypes = [C.POINTER(A.PtSceneDesc), C.POINTER(A.PtRenderParams), C.c_void_p, C.c_int]
         _LIB.oracle_work_counters.argtypes = [C.c_void_p, C.c_int]
+        _LIB.oracle_count_through_tree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     return _LIB
 
 
-def counters(desc, nx, ny, ns, max_depth=25, threads=8):
+def counters(desc, nx, ny, ns, max_depth=25, threads=8, tree=None):
+    """tree: None (the work of the reference's own flat walk), or (nodes, root, cull, prefix, trust): the
+    library's exported LBVH as an (n, 16) uint32 array -- searches are then priced as a replay of that
+    tree over world[:prefix] plus the in-order walk of the rest; trust = let the replay's hit drive the
+    path (for worlds too long for the flat walk)."""
     lib = _load()
+    if tree is not None:
+        nodes, root, cull, prefix, trust = tree
+        nodes = np.ascontiguousarray(nodes, np.uint32)
+        lib.oracle_count_through_tree(nodes.ctypes.data, int(root), int(cull), int(prefix), int(trust))
+    else:
+        lib.oracle_count_through_tree(None, 0, 0, 0, 0)
     p = A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=0, shard_count=1, tile_w=8, tile_h=8)
     img = np.zeros((ny, nx, 3), np.float32)
     lib.oracle_render(desc.ptr, C.byref(p), img.ctypes.data, threads)
     cnt = (C.c_uint64 * len(FIELDS))()
     lib.oracle_work_counters(cnt, len(FIELDS))
+    lib.oracle_count_through_tree(None, 0, 0, 0, 0)
     return dict(zip(FIELDS, [int(v) for v in cnt])), img
 
 

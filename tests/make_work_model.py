@@ -3,30 +3,34 @@
 
 Renders a bounded sample of each configuration with the counting build of the CPU checker
 (oracle/liboracle_count.so, -DPT_ORACLE_COUNT) and divides its counters by the paths traced.
-The counters follow the reference's own evaluation (flat world list, every accepted hit record
-completed), which is the work the roofline figure of bench.py prices the GPU kernel against.
+Two kinds of entries:
+
+* flat walks (cornell, random, final, simple_light): the reference's own evaluation -- flat world
+  list, the reference's BVH with both children always visited, every accepted hit record completed;
+* tree walks (random_lbvh, final_lbvh, trimesh_lbvh): the same scenes searched the way the product
+  searches them, through the LBVH the library built (copied back from the GPU with
+  pt_scene_lbvh_nodes and replayed on the CPU: near child first, pruned by the best distance where
+  that is allowed), plus HBM-side bytes: 64 per node visited + 64 per leaf record tested.
+
 Convention: one FLOP = one fp32 add/sub/mul/compare/min/max/div/sqrt, no FMA credit; libm calls
 and integer operations are reported beside it, not inside it.
 
-Runs on the CPU; needs no GPU (scene descriptors come from the library's host-side factory).
+The flat entries need no GPU; the tree entries need one (the tree is built on the device) and are
+kept from the existing file when none is visible.
 """
-import ctypes as C
 import json
 import os
-import subprocess
 import sys
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # the repository root
 sys.path.insert(0, ROOT)
 import gpupathtracer_amd as pt                     # noqa: E402
-from gpupathtracer_amd import _abi as A            # noqa: E402
+from gpupathtracer_amd import abi                  # noqa: E402
+from tests import _oracle_stats                    # noqa: E402
 
-FIELDS = ["flop", "libm", "iop", "draws", "paths", "world_hits", "rect_tests", "sphere_tests", "triangle_tests",
-          "aabb_tests", "diffuse_scatters", "accepted_hits"]
+OUT = os.path.join(ROOT, "bench", "work_model.json")
 # (key, scene, aspect, nx, ny, spp of the sample, note)
-CONFIGS = [
+FLAT = [
     ("cornell", "cornell", 1.0, 256, 256, 64, "BASELINE configs[2]: Cornell box, depth 25"),
     ("random", "random", 16 / 9, 320, 180, 8, "BASELINE configs[1]: RTIOW, the reference's flat list of 487 spheres"),
     ("final", "final", 16 / 9, 320, 180, 8, "RTNW final scene, reference BVH over 400 boxes + media"),
@@ -34,35 +38,71 @@ CONFIGS = [
 ]
 
 
+def entry(c, note, sample):
+    paths = c["paths"]
+    e = {"note": note, "sample": sample,
+         "flop_per_path": c["flop"] / paths, "libm_calls_per_path": c["libm"] / paths,
+         "integer_ops_per_path": c["iop"] / paths, "rng_draws_per_path": c["draws"] / paths,
+         "closest_hit_searches_per_path": c["world_hits"] / paths, "rect_tests_per_path": c["rect_tests"] / paths,
+         "sphere_tests_per_path": c["sphere_tests"] / paths, "triangle_tests_per_path": c["triangle_tests"] / paths,
+         "aabb_tests_per_path": c["aabb_tests"] / paths, "diffuse_scatters_per_path": c["diffuse_scatters"] / paths,
+         "accepted_hits_per_path": c["accepted_hits"] / paths}
+    if c["tree_nodes"]:
+        e["tree_nodes_visited_per_path"] = c["tree_nodes"] / paths
+        e["tree_leaves_tested_per_path"] = c["tree_leaves"] / paths
+        e["tree_nodes_visited_per_search"] = c["tree_nodes"] / c["world_hits"]
+        e["tree_leaves_tested_per_search"] = c["tree_leaves"] / c["world_hits"]
+        e["bytes_per_path"] = 64.0 * (c["tree_nodes"] + c["tree_leaves"]) / paths
+    return e
+
+
+def tree_configs():
+    sys.path.insert(0, os.path.join(ROOT, "bench"))
+    import configs as bench_configs
+    out = []
+    d = pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH_BINARY)
+    out.append(("random_lbvh", d, d.c.n_world, 1, 0, 320, 180, 8, "BASELINE configs[1] as the product runs it: RTIOW, 487 spheres in the library's LBVH"))
+    d = pt.builtin_scene("final", 16 / 9, earth_rgb=bench_configs.synthetic_earthmap(), accel=abi.ACCEL_LBVH_BINARY)
+    prefix = next(i for i in range(d.c.n_world) if d.c.world[i].type == abi.OBJ_MEDIUM)
+    out.append(("final_lbvh", d, prefix, 1, 0, 320, 180, 8, "BASELINE configs[3] as the product runs it: RTNW final with a 512x256 earth map; the 400 boxes of the "
+                "reference BVH and the shapes before the first medium in the library's LBVH, the media and what follows walked in order"))
+    d = pt.trimesh_scene(1000, 16 / 9)
+    d.c.accel = abi.ACCEL_LBVH_BINARY
+    out.append(("trimesh_lbvh", d, d.c.n_world, 0, 1, 480, 270, 1, "BASELINE configs[4]: 2 000 000 triangles + Cornell enclosure in the library's LBVH "
+                "(no pruning by distance: the reference's triangle t is not one); the replay's own hits drive the paths"))
+    return out
+
+
 def main():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_count.so"])
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_count.so"))
-    lib.oracle_render.argtypes = [C.POINTER(A.PtSceneDesc), C.POINTER(A.PtRenderParams), C.c_void_p, C.c_int]
-    lib.oracle_work_counters.argtypes = [C.c_void_p, C.c_int]
-    out = {"convention": "FLOP = fp32 add/sub/mul/compare/min/max/div/sqrt as the reference evaluates them "
-                         "(flat lists, hit record completed on every accepted hit); no FMA credit; libm and integer ops separate",
+    old = {}
+    if os.path.exists(OUT):
+        old = json.load(open(OUT)).get("configs", {})
+    out = {"convention": "FLOP = fp32 add/sub/mul/compare/min/max/div/sqrt as the reference evaluates them, no FMA credit; libm and integer "
+                         "ops separate.  Flat entries: the reference's own walk (flat lists, its BVH with both children always visited).  "
+                         "*_lbvh entries: the search priced as a replay of the library's exported LBVH (27 FLOP per box test), "
+                         "bytes_per_path = 64 per node visited + 64 per leaf record tested",
            "generator": "tests/make_work_model.py (oracle/pt_oracle.c built with -DPT_ORACLE_COUNT)", "configs": {}}
-    for key, scene, aspect, nx, ny, ns, note in CONFIGS:
+    for key, scene, aspect, nx, ny, ns, note in FLAT:
         desc = pt.builtin_scene(scene, aspect)
-        p = A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=25, shard_index=0, shard_count=1, tile_w=8, tile_h=8)
-        img = np.zeros((ny, nx, 3), np.float32)
-        lib.oracle_render(desc.ptr, C.byref(p), img.ctypes.data, 8)
-        cnt = (C.c_uint64 * len(FIELDS))()
-        lib.oracle_work_counters(cnt, len(FIELDS))
-        c = dict(zip(FIELDS, [int(v) for v in cnt]))
-        paths = c["paths"]
-        assert paths == nx * ny * ns
-        out["configs"][key] = {
-            "note": note, "sample": "%dx%d at %d spp, depth 25" % (nx, ny, ns),
-            "flop_per_path": c["flop"] / paths, "libm_calls_per_path": c["libm"] / paths,
-            "integer_ops_per_path": c["iop"] / paths, "rng_draws_per_path": c["draws"] / paths,
-            "closest_hit_searches_per_path": c["world_hits"] / paths, "rect_tests_per_path": c["rect_tests"] / paths,
-            "sphere_tests_per_path": c["sphere_tests"] / paths, "triangle_tests_per_path": c["triangle_tests"] / paths,
-            "aabb_tests_per_path": c["aabb_tests"] / paths, "diffuse_scatters_per_path": c["diffuse_scatters"] / paths,
-            "accepted_hits_per_path": c["accepted_hits"] / paths,
-        }
+        c, _ = _oracle_stats.counters(desc, nx, ny, ns)
+        assert c["paths"] == nx * ny * ns
+        out["configs"][key] = entry(c, note, "%dx%d at %d spp, depth 25" % (nx, ny, ns))
         print(key, json.dumps(out["configs"][key]), flush=True)
-    with open(os.path.join(ROOT, "bench", "work_model.json"), "w") as f:
+    if pt.device_count() > 0:
+        pt.set_device(0)
+        for key, desc, prefix, cull, trust, nx, ny, ns, note in tree_configs():
+            sc = pt.Scene(desc)
+            nodes = sc.lbvh_nodes()
+            assert len(nodes) > 0
+            c, _ = _oracle_stats.counters(desc, nx, ny, ns, threads=16, tree=(nodes, 0, cull, prefix, trust))
+            out["configs"][key] = entry(c, note, "%dx%d at %d spp, depth 25" % (nx, ny, ns))
+            print(key, json.dumps(out["configs"][key]), flush=True)
+    else:
+        for key in ("random_lbvh", "final_lbvh", "trimesh_lbvh"):
+            if key in old:
+                out["configs"][key] = old[key]
+                print(key, "(kept: no GPU to build the tree on)", flush=True)
+    with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")
 

@@ -215,6 +215,13 @@ def test_two_million_triangles_at_full_scale(oracle):
     rays = np.concatenate([cam, bounce, fall])
     assert len(rays) >= 2000
     ids_o = assert_same_hits(oracle, d, sc, rays, "2M triangles")
+    d.c.accel = abi.ACCEL_LBVH_WIDE                              # the same tree folded to four children per node
+    wide = pt.Scene(d)
+    ids_w, t_w = wide.trace_closest(rays)
+    np.testing.assert_array_equal(ids_w, ids_o)
+    assert_bit_exact(wide.render(480, 270, 1), sc.render(480, 270, 1), "2M triangles, 4-wide against binary")
+    del wide
+    d.c.accel = abi.ACCEL_LBVH
     tri = np.array([d.c.shapes[int(i)].type == abi.SHAPE_TRIANGLE for i in ids_o[ids_o >= 0]])
     assert tri.sum() > 250 and np.unique(ids_o[ids_o >= 0][tri]).size > 200
     # a small frame end to end (every ray of it walks the 2 000 006-entry list in the oracle)

@@ -1006,7 +1006,7 @@ def test_random_worlds_match_the_oracle(oracle, seed):
             if rng.random() < 0.3:                                 # axis-parallel: the direction the reference's base-class light gives
                 rays["d"][i, (axis + 1 + int(rng.integers(0, 2))) % 3] = 0.0
     ref = None
-    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
         g.scalars["accel"] = accel
         g.finalize()
         sc = pt.Scene(g)
@@ -1037,7 +1037,7 @@ def test_random_textured_worlds_through_a_lens_match_the_oracle(oracle, seed):
     near["d"] = (-near["o"] + rng.normal(size=(4000, 3)) * 0.3).astype(np.float32)
     rays = np.concatenate([rays, near])
     ref = None
-    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
         g.scalars["accel"] = accel
         g.finalize()
         sc = pt.Scene(g)
@@ -1049,3 +1049,45 @@ def test_random_textured_worlds_through_a_lens_match_the_oracle(oracle, seed):
             ref = oracle.render(g, 64, 32, 6)
         assert_bit_exact(sc.render(64, 32, 6), ref, "textured world %d accel %d" % (seed, accel))
         assert_bit_exact(sc.render(64, 32, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, "textured world %d accel %d staged" % (seed, accel))
+
+
+WIDE_CASES = [("random", 2.0, None), ("cornell_spheres", 1.0, None), ("simple_light", 2.0, None), ("final", 16 / 9, None),
+              ("final", 16 / 9, "earth"), ("trimesh", 1.0, None), ("cornell", 1.0, None)]
+
+
+@pytest.mark.parametrize("name,aspect,extra", WIDE_CASES)
+def test_four_wide_tree_gives_the_binary_trees_answers(oracle, name, aspect, extra):
+    """PT_ACCEL_LBVH_WIDE: the library's tree with every second level folded away (128-byte nodes, four
+    child boxes).  Same leaves, same tie rule, so the same hits and frames as the binary form and the
+    in-order walk, under every schedule that walks a tree."""
+    tex = np.random.default_rng(12).integers(0, 256, (16, 32, 3), dtype=np.uint8) if extra == "earth" else None
+    if name == "trimesh":
+        d = pt.trimesh_scene(24, aspect)                        # 1 152 triangles: the oracle walks the list entry by entry
+        d.c.accel = abi.ACCEL_LBVH_WIDE
+    elif tex is not None:
+        d = pt.builtin_scene(name, aspect, earth_rgb=tex, accel=abi.ACCEL_LBVH_WIDE)
+    else:
+        d = pt.builtin_scene(name, aspect, accel=abi.ACCEL_LBVH_WIDE)
+    sc = pt.Scene(d)
+    assert len(sc.lbvh_nodes()) > 0
+    rays = np.concatenate([oracle.record_rays(d, 48, 48, 8, 60000), random_rays(np.random.default_rng(21), 30000, -40, 600 if name in ("final", "trimesh", "cornell") else 40)])
+    flat = [i for i in range(d.c.n_shapes) if d.c.shapes[i].type in (abi.SHAPE_RECT_XY, abi.SHAPE_RECT_XZ, abi.SHAPE_RECT_YZ) and d.c.shapes[i].xform_count == 0]
+    if flat:                                                    # rays lying in a rectangle's plane go round the tree
+        rng = np.random.default_rng(22)
+        for i in rng.choice(len(rays), 2000, replace=False):
+            sh = d.c.shapes[flat[int(rng.integers(0, len(flat)))]]
+            axis = {abi.SHAPE_RECT_XY: 2, abi.SHAPE_RECT_XZ: 1, abi.SHAPE_RECT_YZ: 0}[sh.type]
+            rays["o"][i, axis] = sh.p[4]
+            rays["d"][i, axis] = 0.0
+    ids_o, t_o = oracle.trace_closest(d, rays)
+    ids_g, t_g = sc.trace_closest(rays)
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+    ref = oracle.render(d, 80, 48, 4)
+    schedules = [abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL]
+    if name in ("random", "cornell_spheres", "trimesh", "cornell", "simple_light"):
+        schedules.append(abi.SCHEDULE_WALK)                     # the whole world is in the tree
+    for schedule in schedules:
+        assert_bit_exact(sc.render(80, 48, 4, schedule=schedule), ref, "%s wide tree schedule %d" % (name, schedule))
+    d.c.accel = abi.ACCEL_LBVH_BINARY
+    assert_bit_exact(pt.Scene(d).render(80, 48, 4), ref, "%s binary tree" % name)

@@ -33,7 +33,11 @@ CASES = [("cornell", 1.0, None, abi.SCHEDULE_REFILL), ("cornell", 1.0, None, abi
 
 @pytest.mark.parametrize("name,aspect,accel,schedule", CASES)
 def test_noalloc_render_equals_render_device_twice_in_a_row(oracle, name, aspect, accel, schedule):
-    d = pt.builtin_scene(name, aspect, accel=accel)
+    if name == "trimesh":
+        d = pt.trimesh_scene(16, aspect)                        # 512 triangles in the Cornell enclosure
+        d.c.accel = accel
+    else:
+        d = pt.builtin_scene(name, aspect, accel=accel)
     sc = pt.Scene(d)
     # a larger frame first, then a smaller one: a counter left at the first call's total would end the second at once
     for nx, ny, ns in ((200, 120, 3), (64, 40, 4), (8, 8, 1)):

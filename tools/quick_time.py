@@ -9,7 +9,7 @@ from gpupathtracer_amd import abi
 
 name, nx, ny, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 rest = sys.argv[5:]
-accel = abi.ACCEL_LBVH if "lbvh" in rest else abi.ACCEL_LIST
+accel = abi.ACCEL_LBVH if "lbvh" in rest else abi.ACCEL_LBVH_BINARY if "binary" in rest else abi.ACCEL_LBVH_WIDE if "wide" in rest else abi.ACCEL_LIST
 kw = {}
 if "schedule" in rest:
     kw["schedule"] = int(rest[rest.index("schedule") + 1])
