@@ -33,7 +33,7 @@ with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
     FLOP_PER_PATH = {k: v["flop_per_path"] for k, v in json.load(_f)["configs"].items()}
 # HBM bytes one launch moves, from the committed rocprofv3 PMC pass (FETCH_SIZE + WRITE_SIZE with
 # the guide's unit and gfx950 corrections): the frame is written once, the scene stays in cache.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "pmc_cornell1024x512_k_render_tiles.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_cornell1024x512_k_render_tiles.json")
 # fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).  Measured
 # (tools/valu_probe.hip): plain add/mul/fma on vector registers issue at that rate; compares, selects,
 # min/max, integer multiplies, fp64, conversions and the scale / fix-up steps of a divide at half of it.

@@ -17,9 +17,14 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "pt_kernels.h"
 #include "pt_host.h"
 #include "pt_lbvh.h"
+
+using namespace ptd;
+using namespace ptk;
 
 // the specialisations are compiled in pt_k_*.hip
 PT_KERNEL_VARIANTS(extern template struct)
@@ -470,9 +475,10 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     if (want_tree && desc->n_world >= 2 && tree_sized) {
         void* d_nodes = nullptr;
         void* d_wide = nullptr;
-        // Which form the walk reads when the caller leaves it open (MI355X, one frame each; binary / 4-wide): spheres 46.9 / 67.6 ms,
-        // 2 M triangles 17.7 / 18.3 ms, RTNW final 19.2 / 18.6 ms -- four box tests per fetch cost the vector unit
-        // what they save in fetches, except on the final scene's short tree with expensive box leaves.
+        // Which form the walk reads when the caller leaves it open.  Measured on MI355X with both forms under the
+        // same register cap (binary / 4-wide, kernel ms): random spheres 1200x800x64 25.3 / 32.5, 2 M triangles
+        // 3840x2160x16 59.7 / 63.7, RTNW final 800x800x64 31.7 / 29.8 -- four box tests per fetch cost the
+        // vector unit what they save in fetches, except on the final scene's short tree with expensive box leaves.
         const bool auto_wide = (mask & (F_MEDIUM | F_REFBVH)) != 0;
         void** want_wide = (desc->accel == PT_ACCEL_LBVH_WIDE || (desc->accel == PT_ACCEL_LBVH && auto_wide)) ? &d_wide : nullptr;
         int n_nodes = 0, root = 0, rc = PT_OK, depth = 0;

@@ -1,375 +1,22 @@
-// The fused radiance kernels (one lane per pixel, stages fused, path regeneration in-lane) and the
-// closest-hit kernel, as templates over a feature mask and a world walk, with their launchers.
-// Every specialisation is compiled in a translation unit of its own (pt_k_*.hip) so that the
-// library builds in parallel; pt_core.hip declares them extern and picks one per scene.
+// Launchers of the fused radiance kernels (one lane per pixel, stages fused, path regeneration in-lane)
+// and of the closest-hit kernel, one set per (feature mask, world walk).  Declarations only: the
+// kernels and the launchers' bodies are in pt_kernels_impl.h, which only the translation units that
+// compile a specialisation include (pt_k_*.hip, one or a few specialisations each, so that the
+// library builds in parallel).  Code that merely launches them must not see the bodies: it would
+// instantiate -- and then run -- its own copy of every kernel.
 #ifndef PT_KERNELS_H
 #define PT_KERNELS_H
 
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
-
 #include "pt_device.h"
 #include "pt_internal.h"
 
-using namespace ptd;
-using namespace ptk;
-
-// ---- kernels ----------------------------------------------------------------------------------------
-
-// Workgroups per CU the fused kernels are compiled for (a register cap).  Measured on MI355X: the
-// rectangle-scene kernel is bound by vector issue and takes the same time at 5, 6, 7 and 8 (37.5 ms per
-// 512 spp of the 1024^2 Cornell frame): 6 leaves it without spills.  The 2 M-triangle walk gains from
-// occupancy (40.7 -> 33.1 ms at 6, where the LDS traversal stack still fits), the sphere tree likewise
-// (16.9 -> 13.0 ms at 6 although 71 registers then spill).  The kernels that carry the reference's
-// BVH, media and every material (RTNW final) take the same time at 2, 3, 4 and 5 -- 19.1 ms per 16 spp
-// through the library's tree, 40.4 ms through the reference's -- so they get 2: 256 registers, no
-// vector register goes to scratch memory, and the launch's memory traffic is the frame and the scene.
-__host__ __device__ constexpr int fused_min_blocks(uint32_t F)
-{
-#ifdef PT_EXP_BLOCKS            // kernel experiments: -DPT_EXP_BLOCKS=n overrides the table below for the file being compiled
-    return PT_EXP_BLOCKS;
-#endif
-    return (F & F_REFBVH) ? 2 : (F == M_CORNELL) ? 6 : (F == M_SPHERES_LBVH) ? 6 : (F == M_TRIMESH) ? 6 : 1;
-}
-
-// One lane's path tracer state: the pixel's random stream, its running sum and the path in flight.
-struct LaneState {
-    Pcg rng;
-    V3 accum, thr;
-    Ray ray;
-    int x, y;             // render_kernel's pixel coordinates (y counts up from the bottom row)
-    int s, depth;
-    bool fresh;           // the next step starts a new camera sample
-};
-
-__device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs& ra, int x, int ytop, unsigned& i)
-{
-    st.x = x;
-    st.y = ra.ny - 1 - ytop;                              // row 0 of the image is the top
-    i = (unsigned)(ytop * ra.nx + x);                     // = (ny - y - 1) * nx + x   (src/ptMain.cu:178)
-    st.rng.seed((uint64_t)i + ra.seed_offset);            // PcgRng rng(i)              (src/ptMain.cu:183)
-    st.accum = mk(0, 0, 0);
-    st.s = 0;
-    st.fresh = true;
-}
-
-// One bounce of the pixel's sample loop.  Returns true when the pixel's last sample has ended.
-template <uint32_t F, class W>
-__device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, const Rcp& fnx, const Rcp& fny,
-                                          int* my_stack)
-{
-    if (st.fresh) {                                       // render_pixel, src/ptMain.cu:158-160
-        // (x + rand) / nx: the numerator is 0 or at least 2^-32 and the frame size at most 2^31, inside
-        // the range where the shortened division is the whole division (rcp_refined, pt_device.h)
-        float u = quot((float)st.x + st.rng.rand(), fnx);
-        float v = quot((float)st.y + st.rng.rand(), fny);
-        st.ray = camera_ray(sv, u, v, st.rng);
-        st.thr = mk(1, 1, 1);
-        st.depth = 0;
-        st.fresh = false;
-    }
-    bool ended;
-    if (st.depth >= ra.max_depth) {
-        ended = true;                                     // bounce limit: color() returns the running product
-    } else {
-        Hit h;
-        if (world_hit<F, W>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack)) {
-            if constexpr (!is_any_world<W>::value && (F & ~M_CORNELL) == 0) ended = !shade_sig<F, W>(sv, st.ray, h, st.thr, st.rng);
-            else ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
-        } else {
-            shade_miss<F>(sv, st.ray, st.thr);
-            ended = true;
-        }
-        st.depth++;
-    }
-    if (ended) {                                          // accumCol += deNan(color(...)), src/ptMain.cu:46-53,161
-        if (!(st.thr.x == st.thr.x)) st.thr.x = 0;
-        if (!(st.thr.y == st.thr.y)) st.thr.y = 0;
-        if (!(st.thr.z == st.thr.z)) st.thr.z = 0;
-        st.accum = st.accum + st.thr;
-        st.s++;
-        st.fresh = true;
-        return st.s >= ra.ns;
-    }
-    return false;
-}
-
-__device__ __forceinline__ void lane_write_pixel(const LaneState& st, const RenderArgs& ra, unsigned i, float* __restrict__ out)
-{
-    if (ra.raw_sum) {                                     // a sample batch: sums are added across batches, finished later
-        out[3 * (size_t)i + 0] = st.accum.x; out[3 * (size_t)i + 1] = st.accum.y; out[3 * (size_t)i + 2] = st.accum.z;
-        return;
-    }
-    const float inv_ns = 1 / (float)ra.ns;                // accumCol /= float(ns): reciprocal, then multiplies
-    out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, st.accum.x * inv_ns));
-    out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, st.accum.y * inv_ns));
-    out[3 * (size_t)i + 2] = sqrtf(fmaxf(0.0f, st.accum.z * inv_ns));
-}
-
-__device__ __forceinline__ void lane_init(LaneState& st)
-{
-    st.rng.state = 0; st.rng.inc = 1;
-    st.accum = mk(0, 0, 0); st.thr = mk(1, 1, 1);
-    st.ray.o = mk(0, 0, 0); st.ray.d = mk(0, 0, 1); st.ray.time = 0;
-    st.x = 0; st.y = 0; st.s = 0; st.depth = 0; st.fresh = true;
-}
-
-// Fused scheduler, one 8x8 tile per wave and one pixel per lane.  The lanes of a wave start in
-// phase, which keeps the shading branches less divergent when shading dominates a bounce.
-template <uint32_t F, class W>
-__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
-{
-    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
-    const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
-    const int wave = blockIdx.x * 4 + wave_in_block;
-    if (wave >= ra.n_wave_tiles) return;
-    int x, ytop;
-    if (!wave_pixel(ra, wave, lane, x, ytop)) return;
-    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
-    LaneState st;
-    lane_init(st);
-    unsigned i;
-    lane_begin_pixel(st, ra, x, ytop, i);
-    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {}
-    lane_write_pixel(st, ra, i, out);
-}
-
-// One pass of a progressive render: samples [first, first + count) of every owned pixel.  The
-// pixel's random stream and running sum wait in `acc` between passes (passes end on sample
-// boundaries, so no path is ever in flight), which makes any split into passes produce the
-// image of a single launch, and lets a host checkpoint `acc` and resume.  Each pass also
-// writes the estimate so far, sqrt(sum / samples done), the reference's normalisation
-// (src/ptMain.cu:163-166) applied to the samples that exist.
-template <uint32_t F, class W>
-__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneView sv, RenderArgs ra, PtAccumPixel* __restrict__ acc,
-                                                     int first, float* __restrict__ out, int* __restrict__ bad_resume)
-{
-    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
-    const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
-    const int wave = blockIdx.x * 4 + wave_in_block;
-    if (wave >= ra.n_wave_tiles) return;
-    int x, ytop;
-    if (!wave_pixel(ra, wave, lane, x, ytop)) return;
-    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
-    LaneState st;
-    lane_init(st);
-    unsigned i;
-    lane_begin_pixel(st, ra, x, ytop, i);
-    if (first > 0) {
-        const PtAccumPixel a = acc[i];
-        if (a.samples != (uint32_t)first) *bad_resume = 1;    // not the state the earlier passes left: the host reports it
-        st.rng.state = ((uint64_t)a.rng_hi << 32) | a.rng_lo;
-        st.accum = mk(a.sum[0], a.sum[1], a.sum[2]);
-        st.s = first;
-    }
-    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {}      // ra.ns = first + count for this launch
-    PtAccumPixel a;
-    a.rng_lo = (uint32_t)st.rng.state; a.rng_hi = (uint32_t)(st.rng.state >> 32);
-    a.sum[0] = st.accum.x; a.sum[1] = st.accum.y; a.sum[2] = st.accum.z;
-    a.samples = (uint32_t)ra.ns;
-    acc[i] = a;
-    lane_write_pixel(st, ra, i, out);
-}
-
-// Fused scheduler with persistent lanes: a lane that has finished its pixel takes the next pixel
-// slot of the shard (slots are numbered tile by tile, 64 per 8x8 wave tile) from a device counter,
-// so a wave stays full until the shard runs out.  Pays when the closest-hit search, whose loop is
-// uniform over the wave, dominates a bounce.  Which lane traces a pixel does not matter: the
-// pixel's random stream is seeded by its index (src/ptMain.cu:178-184).
-template <uint32_t F, class W>
-__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
-                                                       unsigned* __restrict__ next_slot)
-{
-    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
-    const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
-    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-    const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
-    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
-    LaneState st;
-    lane_init(st);
-    unsigned i = 0;
-    bool have = false;
-    while (true) {
-        if (!have) {
-            const unsigned long long need = __ballot(1);  // one atomic per wave for all lanes that ran dry
-            const int leader = __ffsll((long long)need) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(next_slot, (unsigned)__popcll(need));
-            base = __shfl(base, leader);
-            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const unsigned slot = base + (unsigned)__popcll(need & lower);
-            if (slot >= total_slots) break;               // the shard is exhausted: this lane is done
-            int x, ytop;
-            if (!wave_pixel(ra, (int)(slot >> 6), (int)(slot & 63), x, ytop)) continue;   // slot beyond the image edge
-            lane_begin_pixel(st, ra, x, ytop, i);
-            have = true;
-        }
-        if (lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {
-            lane_write_pixel(st, ra, i, out);
-            have = false;
-        }
-    }
-}
-
-// Fused scheduler for worlds held in the library's LBVH: persistent lanes as in k_render_refill, and
-// the closest-hit search is shared by the wave one tree step at a time.  Lanes whose search has
-// ended wait; when WALK_WAIT_LANES of them wait (or nobody is left walking) the wave leaves the
-// search loop, those lanes shade, scatter or start their next sample (or pixel) and begin their
-// next search, and the wave steps again -- lanes that were still walking simply carry on.  With one
-// search per lane_step call the wave instead runs every search to the end of its longest walk: on
-// the sphere scene 28 % of the VALU lanes did work, on the 2 M-triangle field 8 %.  What each lane
-// computes, and the order of its random draws, is unchanged (the search draws none).
-template <uint32_t F>
-__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneView sv, RenderArgs ra, float* __restrict__ out,
-                                                                           unsigned* __restrict__ next_slot)
-{
-    static_assert((F & F_LBVH) != 0, "the shared walk is the LBVH walk");
-    __shared__ int lds_stack[4 * 64 * LBVH_LDS_STACK];
-    const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
-    int* my_stack = &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane];
-    const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
-    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
-    enum { NEED_PIXEL, NEXT_RAY, WALKING, WALKED, DONE };
-    LaneState st;
-    lane_init(st);
-    LbvhWalk w;
-    lbvh_begin(sv, st.ray, FLT_MAX, w);
-    int spill[LBVH_STACK - LBVH_LDS_STACK];
-    unsigned i = 0;
-    int mode = NEED_PIXEL;
-    while (true) {
-        if (mode == WALKED) {                                 // the rest of the bounce, as in lane_step
-            Hit h;
-            h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
-            bool any = w.any;
-            if (any) { h.t = w.best; h.id = w.best_id; h.face = w.best_face; }
-            if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray))) {     // see accepts_nan: the list, in order
-                const InPlaneHit got = lbvh_in_plane_t<F>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z, st.ray.d.x, st.ray.d.y, st.ray.d.z,
-                                                          st.ray.time, 0.001f, FLT_MAX);
-                if (got.found < 0) any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
-                else {
-                    any = got.found > 0;
-                    h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX;
-                    if (any) { h.t = got.t; h.id = got.id; h.face = got.face; }
-                }
-            }
-            if (F & F_IMAGE) {
-                // a plain sphere whose texture reads uv shows the uv of the hit the in-order walk accepted
-                // before it, which the tree does not know: that ray is searched again in list order
-                if (sv.reads_uv && any && hit_reads_stale_uv<F>(sv, h.id))
-                    any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
-            }
-            bool ended;
-            if (any) {
-                ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
-            } else {
-                shade_miss<F>(sv, st.ray, st.thr);
-                ended = true;
-            }
-            st.depth++;
-            if (!ended && st.depth >= ra.max_depth) ended = true;      // bounce limit: the running product is the sample
-            mode = NEXT_RAY;
-            if (ended) {
-                if (!(st.thr.x == st.thr.x)) st.thr.x = 0;
-                if (!(st.thr.y == st.thr.y)) st.thr.y = 0;
-                if (!(st.thr.z == st.thr.z)) st.thr.z = 0;
-                st.accum = st.accum + st.thr;
-                st.s++;
-                st.fresh = true;
-                if (st.s >= ra.ns) { lane_write_pixel(st, ra, i, out); mode = NEED_PIXEL; }
-            }
-        }
-        if (mode == NEED_PIXEL) {
-            const unsigned long long need = __ballot(1);      // one atomic per wave for all lanes that ran dry
-            const int leader = __ffsll((long long)need) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(next_slot, (unsigned)__popcll(need));
-            base = __shfl(base, leader);
-            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const unsigned slot = base + (unsigned)__popcll(need & lower);
-            int x, ytop;
-            if (slot >= total_slots) mode = DONE;             // the shard is exhausted
-            else if (wave_pixel(ra, (int)(slot >> 6), (int)(slot & 63), x, ytop)) { lane_begin_pixel(st, ra, x, ytop, i); mode = NEXT_RAY; }
-            // else: a slot beyond the image edge; ask again next round
-        }
-        if (mode == NEXT_RAY) {
-            if (st.fresh) {                                   // render_pixel, src/ptMain.cu:158-160
-                float u = quot((float)st.x + st.rng.rand(), fnx);
-                float v = quot((float)st.y + st.rng.rand(), fny);
-                st.ray = camera_ray(sv, u, v, st.rng);
-                st.thr = mk(1, 1, 1);
-                st.depth = 0;
-                st.fresh = false;
-            }
-            lbvh_begin(sv, st.ray, FLT_MAX, w);
-            mode = WALKING;
-        }
-        const int live = __popcll(__ballot(mode != DONE));
-        if (live == 0) break;
-        while (true) {
-            const int walking = __popcll(__ballot(mode == WALKING));
-            if (walking == 0 || live - walking >= ra.walk_wait) break;
-            if (mode == WALKING) {
-                if (lbvh_step<F>(sv, st.ray, 0.001f, FLT_MAX, w, my_stack, spill)) mode = WALKED;
-            }
-        }
-    }
-}
-
-template <uint32_t F, class W>
-__global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay* __restrict__ rays, size_t n,
-                                                       int32_t* __restrict__ prim_id, float* __restrict__ t_out)
-{
-    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
-    const PtRay pr = rays[i];
-    Ray r;
-    r.o = mk(pr.o[0], pr.o[1], pr.o[2]);
-    r.d = mk(pr.d[0], pr.d[1], pr.d[2]);
-    r.time = pr.time;
-    Pcg rng;
-    rng.seed(pr.seed);
-    Hit h;
-    if (world_hit<F, W>(sv, r, 0.001f, FLT_MAX, h, rng, my_stack)) { prim_id[i] = h.id; t_out[i] = h.t; }
-    else { prim_id[i] = PT_ID_MISS; t_out[i] = FLT_MAX; }
-}
-
-
-// Launchers of one specialisation.
 template <uint32_t F, class W>
 struct FusedLaunch {
-    static void render(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
-    {
-        // REFILL: persistent grid of at most 32 waves per CU, the rest of the shard comes from the counter.
-        // A world in the LBVH is searched by the wave-shared walk (which ends a path at the bounce
-        // limit after a shade, so a limit of zero bounces stays with the plain refill kernel).
-        const bool refill = ra.refill != 0;
-        const int tiles4 = (ra.n_wave_tiles + 3) / 4;
-        const dim3 block(256), grid(refill ? std::min(tiles4, 2048) : tiles4);
-        if (ra.refill == 2) {
-            if constexpr ((F & F_LBVH) != 0) hipLaunchKernelGGL((k_render_walk<F>), grid, block, 0, st, sv, ra, out, next_slot);
-        } else if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot);
-        else hipLaunchKernelGGL((k_render_tiles<F, W>), grid, block, 0, st, sv, ra, out);
-    }
-    static void pass(const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume, hipStream_t st)
-    {
-        const dim3 block(256), grid((ra.n_wave_tiles + 3) / 4);
-        hipLaunchKernelGGL((k_render_pass<F, W>), grid, block, 0, st, sv, ra, acc, first, out, bad_resume);
-    }
-    static void trace(const SceneView& sv, const PtRay* rays, size_t n, int32_t* ids, float* ts, hipStream_t st)
-    {
-        const dim3 block(256), grid((unsigned)((n + 255) / 256));
-        hipLaunchKernelGGL((k_trace_closest<F, W>), grid, block, 0, st, sv, rays, n, ids, ts);
-    }
+    static void render(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st);
+    static void pass(const ptd::SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume, hipStream_t st);
+    static void trace(const ptd::SceneView& sv, const PtRay* rays, size_t n, int32_t* ids, float* ts, hipStream_t st);
 };
 
 #endif

@@ -2,8 +2,11 @@
 """Per-kernel register, spill and scratch figures of a HIP source, from the compiler's own
 kernel-resource-usage remarks (compiles the file for gfx950 with the library's flags; no GPU needed).
 
-    python tools/kernel_resources.py gpupathtracer_amd/csrc/pt_core.hip [out.tsv]
+    python tools/kernel_resources.py gpupathtracer_amd/csrc/pt_k_cornell.hip [out.tsv]
+
+Extra compiler flags (kernel experiments) come from the environment: PT_EXTRA_FLAGS="-DPT_EXP_BLOCKS=4".
 """
+import os
 import re
 import subprocess
 import sys
@@ -13,7 +16,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx9
 
 def main():
     src = sys.argv[1]
-    r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"],
+    r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + os.environ.get("PT_EXTRA_FLAGS", "").split() + ["-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"],
                        stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-3000:])

@@ -66,6 +66,16 @@ def main():
     if "WRITE_SIZE" in s:
         der["write_kib_per_launch"] = s["WRITE_SIZE"] / max(1, launches)
     s["_derived"] = der
+    # which build was profiled: bench.py only quotes these numbers for the library they were measured on
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpupathtracer_amd", "libptcore.so")
+    lib = os.environ.get("PT_LIBPTCORE_PATH") or lib
+    if os.path.exists(lib):
+        h = hashlib.sha256()
+        with open(lib, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        s["_libptcore_sha256"] = h.hexdigest()
     s["_command"] = " ".join(cmd)
     s["_kernel_substring"] = needle
     with open(os.path.join(out_dir, "summary.json"), "w") as f:
