@@ -189,12 +189,15 @@ class Comm:
 
 def libm_eval(fn, x, on_device):
     """fn: 0 sin, 1 cos, 2 log, 3 x**5, 4/5 sine/cosine of the combined evaluation, 6 asin, 7 atan2
-    (x then holds (y, x) pairs, shape (n, 2)) -- the library's libm replacements on float32 inputs."""
+    (x then holds (y, x) pairs, shape (n, 2)) -- the library's libm replacements on float32 inputs;
+    8/9 the kernels' in-range square root and sqrtf, 10/11 their in-range quotient and n / d on (n, d)
+    pairs (on the host all four are the plain operation)."""
     x = np.ascontiguousarray(x, np.float32)
-    n = x.size // 2 if int(fn) == 7 else x.size
+    pairs = int(fn) in (7, 10, 11)
+    n = x.size // 2 if pairs else x.size
     out = np.empty(n, np.float32)
     _check(library().pt_libm_eval(int(fn), x.ctypes.data, n, out.ctypes.data, 1 if on_device else 0))
-    return out.reshape(x.shape[:-1]) if int(fn) == 7 else out.reshape(x.shape)
+    return out.reshape(x.shape[:-1]) if pairs else out.reshape(x.shape)
 
 
 class SceneDesc:

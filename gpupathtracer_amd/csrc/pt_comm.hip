@@ -2,9 +2,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstring>
 #include <string>
 
+#include "pt_device.h"
 #include "pt_host.h"
 #include "pt_libm.h"
 
@@ -29,6 +31,8 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (fn == 7) { out[i] = ptm::atan2f_glibc(x[2 * i], x[2 * i + 1]); return; }
+    if (fn == 10) { out[i] = ptd::quot(x[2 * i], ptd::rcp_refined(x[2 * i + 1])); return; }     // the kernels' shortened forms ...
+    if (fn == 11) { out[i] = x[2 * i] / x[2 * i + 1]; return; }                                // ... beside the compiler's full ones
     const float v = x[i];
     float r;
     switch (fn) {
@@ -37,6 +41,8 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
     case 2: r = ptm::logf_glibc(v); break;
     case 3: r = ptm::pow5f_glibc(v); break;
     case 6: r = ptm::asinf_glibc(v); break;
+    case 8: r = ptd::sqrt_tame(v); break;
+    case 9: r = sqrtf(v); break;
     default: { float sn, cs; ptm::sincosf_glibc(v, &sn, &cs); r = fn == 4 ? sn : cs; } break;
     }
     out[i] = r;
@@ -158,7 +164,7 @@ extern "C" void pt_comm_destroy(PtComm* c)
 
 extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device)
 {
-    if (fn < 0 || fn > 7 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
+    if (fn < 0 || fn > 11 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
     if (n == 0) return PT_OK;
     if (!on_device) {
         for (size_t i = 0; i < n; i++) {
@@ -169,6 +175,8 @@ extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on
             case 3: out[i] = ptm::pow5f_glibc(x[i]); break;
             case 6: out[i] = ptm::asinf_glibc(x[i]); break;
             case 7: out[i] = ptm::atan2f_glibc(x[2 * i], x[2 * i + 1]); break;
+            case 8: case 9: out[i] = std::sqrt(x[i]); break;
+            case 10: case 11: out[i] = x[2 * i] / x[2 * i + 1]; break;
             default: { float sn, cs; ptm::sincosf_glibc(x[i], &sn, &cs); out[i] = fn == 4 ? sn : cs; } break;
             }
         }
@@ -176,7 +184,7 @@ extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on
     }
     float *dx = nullptr, *dy = nullptr;
     hipError_t e;
-    const size_t n_in = fn == 7 ? 2 * n : n;
+    const size_t n_in = (fn == 7 || fn == 10 || fn == 11) ? 2 * n : n;
     if ((e = hipMalloc((void**)&dx, n_in * 4)) != hipSuccess) return hip_err(e, "hipMalloc");
     if ((e = hipMalloc((void**)&dy, n * 4)) != hipSuccess) { (void)hipFree(dx); return hip_err(e, "hipMalloc"); }
     int rc = PT_OK;

@@ -217,8 +217,16 @@ std::vector<float> signature_table(const PtSceneDesc* d)
 // The finished surfaces of a signature world, one row per (entry, face) (SigFace in pt_device.h): filled
 // with the kernels' own host-compilable arithmetic.  Only for worlds whose materials are Lambertian or
 // DiffuseLight over constant textures (the rectangle-scene mask admits nothing else).
+//
+// shade_sig divides in the shortened form (rcp_refined), which wants its numerators either zero or
+// not too small: a table is only made when every normal component is 0 or at least 2^-20 in
+// magnitude (a box turned by less than a millionth of a radian fails), every colour component 0
+// or within [2^-20, 2^20], and the light's rectangle within the bound of the world's own constants.
 bool signature_faces(const PtSceneDesc* d, std::vector<float>* out)
 {
+    auto zero_or_sizable = [](float v, float hi) { const float a = std::fabs(v); return v == 0.0f || (a >= 0x1p-20f && a <= hi); };
+    if (d->n_lights != 1 || d->lights[0] < 0 || d->lights[0] >= d->n_shapes) return false;
+    for (float v : d->shapes[d->lights[0]].p) if (!(std::fabs(v) <= ptd::RCP_BIG)) return false;
     out->assign((size_t)d->n_world * 8 * ptd::SIG_FACE, 0.0f);
     for (int i = 0; i < d->n_world; i++) {
         const PtShape& s = d->shapes[d->world[i].index];
@@ -240,6 +248,8 @@ bool signature_faces(const PtSceneDesc* d, std::vector<float>* out)
             q[12] = tx.color[0]; q[13] = tx.color[1]; q[14] = tx.color[2];
             const int32_t mt = m.type;
             std::memcpy(&q[15], &mt, sizeof mt);
+            for (int k = 0; k < 3; k++)
+                if (!zero_or_sizable(q[k], 2.0f) || !zero_or_sizable(q[9 + k], 2.0f) || !(tx.color[k] >= 0.0f) || !zero_or_sizable(tx.color[k], 0x1p20f)) return false;
         }
     }
     return true;

@@ -170,14 +170,18 @@ __device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
     ptm::sincosf_glibc(theta, &sn, &cs);
     return mk(r * cs, r * sn, 0.0f);
 }
+// r1, r2: results of Pcg::rand(), i.e. multiples of 2^-32 in [0, 1): both square roots take an
+// argument that is 0 or at least 2^-32 (sqrt_tame; the functions are declared further down).
+__device__ __forceinline__ float sqrt_tame(float x);
 __device__ __forceinline__ V3 random_cosine_direction(float r1, float r2)
 {
-    float z = sqrtf(1 - r2);
+    float z = sqrt_tame(1 - r2);
     float phi = 2 * PI_F * r1;
     float sn, cs;
     ptm::sincosf_glibc(phi, &sn, &cs);
-    float x = cs * 2 * sqrtf(r2);
-    float y = sn * 2 * sqrtf(r2);
+    const float root = sqrt_tame(r2);
+    float x = cs * 2 * root;
+    float y = sn * 2 * root;
     return mk(x, y, z);
 }
 __device__ __forceinline__ V3 random_cosine_direction(Pcg& g)
@@ -298,8 +302,22 @@ __device__ __forceinline__ float quot(float n, const Rcp& c)
     return __builtin_fmaf(e, c.r, q);
 }
 __device__ __forceinline__ float quot(float n, float d) { return n / d; }
+// sqrtf for an argument that is +0 or lies in [2^-96, FLT_MAX].  The correctly rounded sequence the
+// compiler emits is: scale the argument up if it is below 2^-96, v_sqrt, step the root one ulp down and
+// one ulp up wherever the residual asks for it, scale back, and hand zeros and infinity through.  In
+// the stated range the scale is 1 and nothing is handed through (+0 leaves the two steps as +0: the
+// stepped-down root is a NaN and the stepped-up one gives a residual of 0), so the middle is the whole.
+__device__ __forceinline__ float sqrt_tame(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+    const float r = (0.0f >= r_down) ? down : s;
+    return (0.0f < r_up) ? up : r;
+}
+constexpr float SQRT_TAME_MIN = 0x1p-96f;
 // The range test for `count` denominators at once and for the origin the numerators are formed from.
-constexpr float RCP_D_MIN = 0x1p-30f, RCP_BIG = 0x1p58f, RCP_TMIN_MIN = 0x1p-20f;
+constexpr float RCP_D_MIN = 0x1p-30f, RCP_BIG = 0x1p58f, RCP_TMIN_MIN = 0x1p-20f, SHADE_DIR_MAX = 0x1p20f;
 
 // X?Rectangle::hit (src/ptRectangle.cu:12-28,66-82,120-136): inclusive range.
 // (ok,dk) plane axis, (oa,da) and (ob,db) the two in-plane axes; dk is the direction component
@@ -1737,18 +1755,57 @@ __device__ __forceinline__ bool shade_sig(const SceneView& sv, Ray& ray, const H
     const bool pick_light = g.rand() < 0.5f;                        // MixturePdf::generate, include/ptPDF.h:94-100 (see shade)
     const float d1 = g.rand();
     const float d2 = g.rand();
+    const PtShape* ls = &sv.shapes[sv.lights[0]];
     if (pick_light) {                                               // include/ptRectangle.h:91-95
-        const PtShape* ls = &sv.shapes[sv.lights[0]];
         V3 rp = mk(ls->p[0] + d2 * (ls->p[1] - ls->p[0]), ls->p[4], ls->p[2] + d1 * (ls->p[3] - ls->p[2]));
         dir = rp - p;
     } else {
         dir = onb_local(uvw, random_cosine_direction(d1, d2));
     }
-    const float pdf_value = 0.5f * lights_pdf<F>(sv, p, dir) + 0.5f * cosine_pdf_value(uvw, dir);
-    const float cosine = dot(n, unit(dir));
-    const float spdf = (cosine < 0) ? 0.0f : cosine / PI_F;
+    // The rest is shade()'s arithmetic: mixture pdf value, scattering pdf, attenuation.  A direction
+    // whose components all lie in [2^-30, 2^20] in magnitude (anything but an axis-parallel or a
+    // runaway one) and a hit point within 2^58 put every denominator below into the range where the
+    // shortened division is the whole division (rcp_refined): the length, the direction's own y, pi.
+    // The numerators are the components again, and cosines that are either +0 (a product sum that
+    // cancels) or at least 2^-95 in magnitude, because the table's normals have components that are
+    // 0 or at least 2^-20 (checked when the table is built).  The length is then computed once for the
+    // light's pdf and for both cosines, its argument inside sqrt_tame's range.
+    const float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+    const bool tame = fminf(fminf(ax, ay), az) >= RCP_D_MIN && fmaxf(fmaxf(ax, ay), az) <= SHADE_DIR_MAX && fabsf(p.y) <= RCP_BIG;
+    float pdf_value, spdf;
+    if (tame) {
+        const Rcp over_pi = rcp_refined(PI_F);
+        const float len2 = sqlen(dir);
+        const Rcp over_len = rcp_refined(sqrt_tame(len2));
+        const V3 u = mk(quot(dir.x, over_len), quot(dir.y, over_len), quot(dir.z, over_len));
+        float t, light_pdf = 0;
+        if (rect_ok(p.y, rcp_refined(dir.y), p.x, dir.x, p.z, dir.z, ls->p[0], ls->p[1], ls->p[2], ls->p[3], ls->p[4], 0.001f, FLT_MAX, t)) {
+            const float area = (ls->p[1] - ls->p[0]) * (ls->p[3] - ls->p[2]);     // include/ptRectangle.h:77-89
+            const float dist_sqrd = t * t * len2;
+            const float cosine = fabsf(u.y);                        // dot(v, (0,1,0)) is v.y itself for a finite v with v.y != 0
+            light_pdf = dist_sqrd / (cosine * area);
+        }
+        const float cos_w = dot(u, uvw.w), cos_n = dot(n, u);
+        const float cosine_pdf = (cos_w > 0) ? quot(cos_w, over_pi) : 0.0f;       // include/ptPDF.h:46-53
+        pdf_value = 0.5f * light_pdf + 0.5f * cosine_pdf;
+        spdf = (cos_n < 0) ? 0.0f : quot(cos_n, over_pi);
+    } else {
+        pdf_value = 0.5f * lights_pdf<F>(sv, p, dir) + 0.5f * cosine_pdf_value(uvw, dir);
+        const float cos_n = dot(n, unit(dir));
+        spdf = (cos_n < 0) ? 0.0f : cos_n / PI_F;
+    }
     const V3 emitted = mk(0, 0, 0);
-    thr = thr * (emitted + (colour * spdf) / pdf_value);
+    const V3 num = colour * spdf;
+    // The last division: the pdf value must be in the denominator's range, and a non-zero numerator
+    // at least 2^-103 -- colours are 0 or at least 2^-20 (checked with the table), so spdf >= 2^-80 will do.
+    V3 ratio;
+    if (tame && pdf_value >= RCP_D_MIN && pdf_value <= RCP_BIG && (spdf == 0.0f || spdf >= 0x1p-80f)) {
+        const Rcp over_pdf = rcp_refined(pdf_value);
+        ratio = mk(quot(num.x, over_pdf), quot(num.y, over_pdf), quot(num.z, over_pdf));
+    } else {
+        ratio = num / pdf_value;
+    }
+    thr = thr * (emitted + ratio);
     ray.o = p; ray.d = dir;           // time is kept (src/ptMain.cu:123,130)
     return true;
 }

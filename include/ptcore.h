@@ -420,7 +420,11 @@ void pt_comm_destroy(PtComm* comm);
  * (the reference's Sin/Cos/Log/Pow wrappers, include/ptMath.h:34-45); fn 4 and 5 are the sine and
  * the cosine from the combined evaluation the direction samplers use, equal to fn 0 and 1; fn 6 asin; fn 7 atan2,
  * where x holds n (y, x) pairs, 2 * n floats (MovingSphere's get_uv, include/ptSphere.h:22-28).  on_device != 0 runs the
- * device code on the current HIP device, otherwise the same source compiled for the host. */
+ * device code on the current HIP device, otherwise the same source compiled for the host.
+ * fn 8 to 11 expose the kernels' shortened arithmetic next to the compiler's full sequences, for tests
+ * of the ranges the kernels use them in: 8 the square root for arguments that are +0 or at least
+ * 2^-96, 9 sqrtf; 10 the quotient n / d for 2^-30 <= |d| <= 2^60 and 2^-103 <= |n| <= 2^60, 11 n / d,
+ * both on n (numerator, denominator) pairs.  On the host all four are the plain operation. */
 int  pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device);
 
 #ifdef __cplusplus

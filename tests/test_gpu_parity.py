@@ -200,6 +200,39 @@ def test_device_libm_matches_glibc(oracle):
     assert same.all(), (yx[~same][:5], a[~same][:5], b[~same][:5])
 
 
+def test_shortened_square_root_and_quotient_are_the_full_ones_in_their_ranges():
+    """The kernels' in-range sqrt (arguments +0 or >= 2^-96) and quotient (2^-30 <= |d| <= 2^60,
+    2^-103 <= |n| <= 2^60) against the compiler's full sequences on the device and IEEE on the host."""
+    rng = np.random.default_rng(11)
+    lo, hi = np.float32(2.0 ** -96).view(np.uint32), np.float32(np.finfo(np.float32).max).view(np.uint32)
+    r2 = (rng.integers(0, 2 ** 32, 1_000_000, dtype=np.uint64).astype(np.float32) * np.float32(2.0 ** -32)).clip(max=np.float32(0.99999994))
+    squares = (rng.integers(1, 4096, 100_000).astype(np.float32) * np.float32(2.0) ** rng.integers(-40, 40, 100_000).astype(np.float32)) ** 2
+    x = np.concatenate([rng.integers(int(lo), int(hi) + 1, 4_000_000, dtype=np.uint32).view(np.float32), r2, np.float32(1) - r2,
+                        np.arange(65536, dtype=np.float32) * np.float32(2.0 ** -32), squares,
+                        np.nextafter(squares, np.float32(0)), np.nextafter(squares, np.float32(np.inf)),
+                        np.array([0.0, 2.0 ** -96, np.finfo(np.float32).max, 1.0, 2.0, 3.0, 0.25], np.float32)]).astype(np.float32)
+    short, full, host = pt.libm_eval(8, x, True), pt.libm_eval(9, x, True), np.sqrt(x)
+    assert (bits(short) == bits(full)).all() and (bits(short) == bits(host)).all()
+
+    def signed_log_uniform(n, e0, e1):
+        return (np.float32(2.0) ** rng.uniform(e0, e1, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    edges_d = np.array([2.0 ** -30, -2.0 ** -30, 2.0 ** 60, -2.0 ** 60, 1.0, 3.0, np.pi, 1 / 3], np.float32)
+    edges_n = np.array([2.0 ** -103, -2.0 ** -103, 2.0 ** 60, -2.0 ** 60, 1.0, 7.0, 1e-20, 0.1], np.float32)
+    grid = np.stack(np.meshgrid(edges_n, np.concatenate([edges_d, np.nextafter(edges_d, np.float32(1))])), -1).reshape(-1, 2)
+    nd = np.concatenate([np.stack([signed_log_uniform(3_000_000, -103, 60), signed_log_uniform(3_000_000, -30, 60)], -1),
+                         np.stack([signed_log_uniform(1_000_000, -12, 12), signed_log_uniform(1_000_000, -12, 12)], -1),
+                         np.stack([signed_log_uniform(500_000, -30, 1), np.full(500_000, np.pi, np.float32)], -1), grid]).astype(np.float32)
+    short, full = pt.libm_eval(10, nd, True), pt.libm_eval(11, nd, True)
+    with np.errstate(over="ignore", under="ignore"):
+        host = nd[:, 0] / nd[:, 1]
+    bad = bits(short) != bits(full)
+    assert not bad.any(), (nd[bad][:5], short[bad][:5], full[bad][:5])
+    assert (bits(full) == bits(host)).all()
+    # +0 over a positive denominator stays +0 (a cosine that cancels to zero)
+    z = pt.libm_eval(10, np.array([[0.0, np.pi], [0.0, 2.5]], np.float32), True)
+    assert (bits(z) == 0).all()
+
+
 def test_render_into_device_memory_and_single_rank_rccl(oracle):
     d = pt.builtin_scene("cornell", 1.0)
     sc = pt.Scene(d)
