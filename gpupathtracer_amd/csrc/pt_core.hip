@@ -462,7 +462,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     v.ambient_type = desc->ambient_type;
     std::memcpy(v.ambient, desc->ambient_color, sizeof v.ambient);
     std::memcpy(v.camera, desc->camera, sizeof v.camera);
-    v.lbvh = nullptr; v.lbvh_root = 0; v.lbvh_cull = 0;
+    v.lbvh = nullptr; v.lbvh_root = 0; v.lbvh_cull = 0; v.leaf_vote = 1;
     v.sig = nullptr;
     sc->n_shapes = desc->n_shapes;
     sc->n_media = desc->n_media;
@@ -568,6 +568,7 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
             v.lbvh = static_cast<const LbvhNode*>(d_nodes);
             v.lbvh_root = root;
             v.lbvh_cull = (mask & F_TRIANGLE) ? 0 : 1;
+            v.leaf_vote = (mask & F_TRIANGLE) ? (desc->n_shapes >= 100000 ? 8 : 1) : (mask & (F_MEDIUM | F_REFBVH)) ? 16 : 12;   // see lbvh_voted_step
             sc->lbvh_nodes = n_nodes;
             mask |= F_LBVH;
             if (d_wide) {
@@ -710,13 +711,14 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // mostly the (wave-uniform) closest-hit search, not when shading dominates it.
     ra.refill = (p->schedule == PT_SCHEDULE_REFILL) ||
                 (p->schedule == PT_SCHEDULE_AUTO && ((sc->mask & (ptd::F_LBVH | ptd::F_REFBVH)) || sc->view.n_world > 16));
-    // Measured (MI355X): spheres in the LBVH, 1920x1080: TILES 13.0 ms, REFILL 13.9, WALK 14.4 (shading,
-    // not the search, is most of a bounce there); 2 M triangles in the LBVH, 3840x2160: TILES 31.2,
-    // REFILL 28.2, WALK 18.3 with 48 waiting lanes (32: 21.7, 40: 19.2, 44: 18.5, 52: 18.7).
-    if (p->schedule == PT_SCHEDULE_AUTO && (sc->variant == V_SPHERES_LBVH || sc->variant == V_SPHERES_LBVH4)) ra.refill = 0;
+    // Measured (MI355X, kernel ms; TILES / REFILL / WALK): spheres in the LBVH, 1920x1080x64: 48.0 / 49.7 / 43.4;
+    // RTNW final through the LBVH, 1920x1080x64: 61.0 / 65.7 / -; 2 M triangles in the LBVH, 3840x2160x16:
+    // 133 / - / 55.0 with 48 waiting lanes (40: 55.9, 56: 65.9; spheres 24: 49.0, 32: 45.5, 40: 44.5, 56: 44.6).
+    const bool whole_world_in_tree = (sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1;
+    if (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & (ptd::F_MEDIUM | ptd::F_REFBVH))) ra.refill = 0;
+    if (p->schedule == PT_SCHEDULE_AUTO && (sc->variant == V_SPHERES_LBVH4 || sc->variant == V_SPHERES_LBVH)) ra.refill = 0;
     if (p->schedule == PT_SCHEDULE_WALK ||
-        (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & ptd::F_TRIANGLE) &&
-         sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1)) ra.refill = 2;
+        (p->schedule == PT_SCHEDULE_AUTO && whole_world_in_tree && ((sc->mask & ptd::F_TRIANGLE) || (sc->variant == V_SPHERES_LBVH && sc->view.n_world >= 64)))) ra.refill = 2;   // a 7-sphere room: TILES 47.9, WALK 50.8
     ra.walk_wait = 48;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);

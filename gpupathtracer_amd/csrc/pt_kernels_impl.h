@@ -316,9 +316,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
         while (true) {
             const int walking = __popcll(__ballot(mode == WALKING));
             if (walking == 0 || live - walking >= ra.walk_wait) break;
-            if (mode == WALKING) {
-                if (lbvh_step<F>(sv, st.ray, 0.001f, FLT_MAX, w, my_stack, spill)) mode = WALKED;
-            }
+            if (lbvh_voted_step<F>(sv, st.ray, 0.001f, FLT_MAX, w, my_stack, spill, mode == WALKING)) mode = WALKED;
         }
     }
 }

@@ -647,9 +647,9 @@ def test_shared_walk_schedule_bit_exact(oracle, which):
     for s in range(3):
         acc += sc.render(100, 60, 4, shard_index=s, shard_count=3, tile=(8, 8), schedule=abi.SCHEDULE_WALK)
     assert_bit_exact(acc, full, which + " shards through the shared walk")
-    # AUTO picks it for triangles in the tree, not for spheres
+    # AUTO picks it for triangles in the tree and for sphere worlds of some size, not for a room of seven spheres
     sc.render(16, 16, 1)
-    assert (sc.stats().schedule == abi.SCHEDULE_WALK) == which.startswith("trimesh")
+    assert (sc.stats().schedule == abi.SCHEDULE_WALK) == (which != "cornell_spheres")
     # a bounce limit of zero has no search to share
     with pytest.raises(pt.PtError):
         sc.render(8, 8, 1, 0, schedule=abi.SCHEDULE_WALK)
