@@ -581,12 +581,14 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     sc->mask = mask;
     sc->variant = pick_variant(mask);
     v.sig_faces = nullptr;
+    for (float& f : v.sig_light) f = 0.0f;
     std::vector<float> faces;
     // the signature kernels shade from the face table and sample the one light shape: both must exist
     if (sc->variant == V_CORNELL && world_matches(desc, CornellWorld{}) && desc->n_lights == 1 && signature_faces(desc, &faces)) {
         const std::vector<float> table = signature_table(desc);
         if (!upload(sc, table.data(), table.size(), &v.sig, "upload signature table") ||
             !upload(sc, faces.data(), faces.size(), &v.sig_faces, "upload signature faces")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+        for (int k = 0; k < 5; k++) v.sig_light[k] = desc->shapes[desc->lights[0]].p[k];
         sc->variant = V_CORNELL_WORLD;
     }
     if (sc->variant < 0) { pt::set_error("pt_scene_create: no kernel specialisation covers this scene"); pt_scene_destroy(sc); return PT_ERR_UNSUPPORTED; }

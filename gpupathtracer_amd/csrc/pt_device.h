@@ -84,6 +84,7 @@ struct SceneView {
     const LbvhNode4*  lbvh4;    // the 4-wide form of the same tree (kernels compiled with F_LBVH4 walk this one), or nullptr
     const float*      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
     const float*      sig_faces;    // signature walk: SIG_FACE floats per (entry, face): the finished surface (see shade_sig); nullptr = none
+    float             sig_light[5];  // signature walk: x0, x1, z0, z1, y of the one XZ rectangle that is the light (shade_sig)
     const int32_t*    lbvh_order;   // per shape: its place in the sequence of tests the in-order walk makes (nullptr: the shape index)
     const int32_t*    lbvh_group;   // per shape: the reference BVH it is a leaf of, -1 for a list entry (with lbvh_order)
     const float*      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
@@ -1748,9 +1749,9 @@ __device__ __forceinline__ bool shade(const SceneView& sv, Ray& ray, const Hit& 
 // DiffuseLight materials over constant textures, one bare XZ rectangle as the light shape.  The
 // same arithmetic as shade() from the point where normal, basis and colour are known.
 template <uint32_t F, class W>
-__device__ __forceinline__ bool shade_sig(const SceneView& sv, Ray& ray, const Hit& h, V3& thr, Pcg& g)
+__device__ __forceinline__ bool shade_sig(const SceneView& sv, const float4* faces, Ray& ray, const Hit& h, V3& thr, Pcg& g)
 {
-    const float4* row = reinterpret_cast<const float4*>(sv.sig_faces + SIG_FACE * h.sig_code);
+    const float4* row = faces + (SIG_FACE / 4) * h.sig_code;       // the workgroup's copy of SceneView::sig_faces
     const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
     const V3 n = mk(r0.x, r0.y, r0.z);
     Onb uvw;
@@ -1780,9 +1781,9 @@ __device__ __forceinline__ bool shade_sig(const SceneView& sv, Ray& ray, const H
     const bool pick_light = g.rand() < 0.5f;                        // MixturePdf::generate, include/ptPDF.h:94-100 (see shade)
     const float d1 = g.rand();
     const float d2 = g.rand();
-    const PtShape* ls = &sv.shapes[sv.lights[0]];
+    const float* lp = sv.sig_light;                                 // the light shape's constants, held in the view itself
     if (pick_light) {                                               // include/ptRectangle.h:91-95
-        V3 rp = mk(ls->p[0] + d2 * (ls->p[1] - ls->p[0]), ls->p[4], ls->p[2] + d1 * (ls->p[3] - ls->p[2]));
+        V3 rp = mk(lp[0] + d2 * (lp[1] - lp[0]), lp[4], lp[2] + d1 * (lp[3] - lp[2]));
         dir = rp - p;
     } else {
         dir = onb_local(uvw, random_cosine_direction(d1, d2));
@@ -1804,8 +1805,8 @@ __device__ __forceinline__ bool shade_sig(const SceneView& sv, Ray& ray, const H
         const Rcp over_len = rcp_refined(sqrt_tame(len2));
         const V3 u = mk(quot(dir.x, over_len), quot(dir.y, over_len), quot(dir.z, over_len));
         float t, light_pdf = 0;
-        if (rect_ok(p.y, rcp_refined(dir.y), p.x, dir.x, p.z, dir.z, ls->p[0], ls->p[1], ls->p[2], ls->p[3], ls->p[4], 0.001f, FLT_MAX, t)) {
-            const float area = (ls->p[1] - ls->p[0]) * (ls->p[3] - ls->p[2]);     // include/ptRectangle.h:77-89
+        if (rect_ok(p.y, rcp_refined(dir.y), p.x, dir.x, p.z, dir.z, lp[0], lp[1], lp[2], lp[3], lp[4], 0.001f, FLT_MAX, t)) {
+            const float area = (lp[1] - lp[0]) * (lp[3] - lp[2]);     // include/ptRectangle.h:77-89
             const float dist_sqrd = t * t * len2;
             const float cosine = fabsf(u.y);                        // dot(v, (0,1,0)) is v.y itself for a finite v with v.y != 0
             light_pdf = dist_sqrd / (cosine * area);

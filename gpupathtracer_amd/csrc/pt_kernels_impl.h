@@ -33,6 +33,21 @@ __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
     return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 6 : 1;
 }
 
+// Signature worlds shade from the face table (shade_sig): every workgroup keeps a copy in LDS, 64 bytes
+// per (entry, face), read with a lane's own index once per bounce -- a global load there is the
+// longest wait of the bounce when few waves share a SIMD.
+template <uint32_t F, class W> struct FaceTable { static constexpr int float4s = 1; static constexpr bool used = false; };
+template <uint32_t F, int... K> struct FaceTable<F, WorldSig<K...>> { static constexpr bool used = (F & ~M_CORNELL) == 0; static constexpr int float4s = used ? (int)sizeof...(K) * 8 * (SIG_FACE / 4) : 1; };
+template <uint32_t F, class Sig> struct FaceTable<F, Branchless<Sig>> : FaceTable<F, Sig> {};
+template <uint32_t F, class W>
+__device__ __forceinline__ void face_table_to_lds(const SceneView& sv, float4* lds)
+{
+    if constexpr (FaceTable<F, W>::used) {
+        for (int k = threadIdx.x; k < FaceTable<F, W>::float4s; k += blockDim.x) lds[k] = reinterpret_cast<const float4*>(sv.sig_faces)[k];
+        __syncthreads();
+    }
+}
+
 // One lane's path tracer state: the pixel's random stream, its running sum and the path in flight.
 struct LaneState {
     Pcg rng;
@@ -57,7 +72,7 @@ __device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs
 // One bounce of the pixel's sample loop.  Returns true when the pixel's last sample has ended.
 template <uint32_t F, class W>
 __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, const Rcp& fnx, const Rcp& fny,
-                                          int* my_stack)
+                                          int* my_stack, const float4* faces)
 {
     if (st.fresh) {                                       // render_pixel, src/ptMain.cu:158-160
         // (x + rand) / nx: the numerator is 0 or at least 2^-32 and the frame size at most 2^31, inside
@@ -75,7 +90,7 @@ __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs&
     } else {
         Hit h;
         if (world_hit<F, W>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack)) {
-            if constexpr (!is_any_world<W>::value && (F & ~M_CORNELL) == 0) ended = !shade_sig<F, W>(sv, st.ray, h, st.thr, st.rng);
+            if constexpr (!is_any_world<W>::value && (F & ~M_CORNELL) == 0) ended = !shade_sig<F, W>(sv, faces, st.ray, h, st.thr, st.rng);
             else ended = !shade<F>(sv, st.ray, h, st.thr, st.rng);
         } else {
             shade_miss<F>(sv, st.ray, st.thr);
@@ -121,6 +136,8 @@ template <uint32_t F, class W>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(SceneView sv, RenderArgs ra, float* __restrict__ out)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ float4 faces[FaceTable<F, W>::float4s];
+    face_table_to_lds<F, W>(sv, faces);            // before any lane leaves: the copy ends in a barrier
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wave_in_block;
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(Scene
     lane_init(st);
     unsigned i;
     lane_begin_pixel(st, ra, x, ytop, i);
-    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {}
+    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces)) {}
     lane_write_pixel(st, ra, i, out);
 }
 
@@ -148,6 +165,8 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
                                                      int first, float* __restrict__ out, int* __restrict__ bad_resume)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ float4 faces[FaceTable<F, W>::float4s];
+    face_table_to_lds<F, W>(sv, faces);            // before any lane leaves: the copy ends in a barrier
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wave_in_block;
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
         st.accum = mk(a.sum[0], a.sum[1], a.sum[2]);
         st.s = first;
     }
-    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {}      // ra.ns = first + count for this launch
+    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces)) {}      // ra.ns = first + count for this launch
     PtAccumPixel a;
     a.rng_lo = (uint32_t)st.rng.state; a.rng_hi = (uint32_t)(st.rng.state >> 32);
     a.sum[0] = st.accum.x; a.sum[1] = st.accum.y; a.sum[2] = st.accum.z;
@@ -186,6 +205,8 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
                                                        unsigned* __restrict__ next_slot)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ float4 faces[FaceTable<F, W>::float4s];
+    face_table_to_lds<F, W>(sv, faces);            // before any lane leaves: the copy ends in a barrier
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
             lane_begin_pixel(st, ra, x, ytop, i);
             have = true;
         }
-        if (lane_step<F, W>(sv, ra, st, fnx, fny, my_stack)) {
+        if (lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces)) {
             lane_write_pixel(st, ra, i, out);
             have = false;
         }
