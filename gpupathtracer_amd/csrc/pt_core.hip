@@ -485,12 +485,12 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     if (want_tree && desc->n_world >= 2 && tree_sized) {
         void* d_nodes = nullptr;
         void* d_wide = nullptr;
-        // Which form the walk reads when the caller leaves it open.  Measured on MI355X with both forms under the
-        // same register cap (binary / 4-wide, kernel ms): random spheres 1200x800x64 25.3 / 32.5, 2 M triangles
-        // 3840x2160x16 59.7 / 63.7, RTNW final 800x800x64 31.7 / 29.8 -- four box tests per fetch cost the
-        // vector unit what they save in fetches, except on the final scene's short tree with expensive box leaves.
-        const bool auto_wide = (mask & (F_MEDIUM | F_REFBVH)) != 0;
-        void** want_wide = (desc->accel == PT_ACCEL_LBVH_WIDE || (desc->accel == PT_ACCEL_LBVH && auto_wide)) ? &d_wide : nullptr;
+        // Which form the walk reads when the caller leaves it open: the binary one.  Measured on MI355X with both
+        // forms under the same register cap and schedule (binary / 4-wide, kernel ms): random spheres
+        // 1920x1080x64 47.7 / 62.0, 2 M triangles 3840x2160x16 59.7 / 63.7, RTNW final 1920x1080x64 62.2 / 63.2 --
+        // four box tests per fetch cost the vector unit more than the saved fetches give back.  The 4-wide
+        // form is built and walked on request (PT_ACCEL_LBVH_WIDE).
+        void** want_wide = desc->accel == PT_ACCEL_LBVH_WIDE ? &d_wide : nullptr;
         int n_nodes = 0, root = 0, rc = PT_OK, depth = 0;
         bool built = false;
         LbvhPlan plan;
@@ -712,13 +712,11 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // Refilling keeps waves full but puts their lanes out of phase; that pays when a bounce is
     // mostly the (wave-uniform) closest-hit search, not when shading dominates it.
     ra.refill = (p->schedule == PT_SCHEDULE_REFILL) ||
-                (p->schedule == PT_SCHEDULE_AUTO && ((sc->mask & (ptd::F_LBVH | ptd::F_REFBVH)) || sc->view.n_world > 16));
+                (p->schedule == PT_SCHEDULE_AUTO && !(sc->mask & ptd::F_LBVH) && ((sc->mask & ptd::F_REFBVH) || sc->view.n_world > 16));
     // Measured (MI355X, kernel ms; TILES / REFILL / WALK): spheres in the LBVH, 1920x1080x64: 48.0 / 49.7 / 43.4;
     // RTNW final through the LBVH, 1920x1080x64: 61.0 / 65.7 / -; 2 M triangles in the LBVH, 3840x2160x16:
     // 133 / - / 55.0 with 48 waiting lanes (40: 55.9, 56: 65.9; spheres 24: 49.0, 32: 45.5, 40: 44.5, 56: 44.6).
     const bool whole_world_in_tree = (sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1;
-    if (p->schedule == PT_SCHEDULE_AUTO && (sc->mask & ptd::F_LBVH) && (sc->mask & (ptd::F_MEDIUM | ptd::F_REFBVH))) ra.refill = 0;
-    if (p->schedule == PT_SCHEDULE_AUTO && (sc->variant == V_SPHERES_LBVH4 || sc->variant == V_SPHERES_LBVH)) ra.refill = 0;
     if (p->schedule == PT_SCHEDULE_WALK ||
         (p->schedule == PT_SCHEDULE_AUTO && whole_world_in_tree && ((sc->mask & ptd::F_TRIANGLE) || (sc->variant == V_SPHERES_LBVH && sc->view.n_world >= 64)))) ra.refill = 2;   // a 7-sphere room: TILES 47.9, WALK 50.8
     ra.walk_wait = 48;

@@ -89,8 +89,8 @@ enum PtAccel {
                               /* the reference's rectangle, box and triangle tests accept a NaN t    */
                               /* (src/ptRectangle.cu:15: a ray lying in a rectangle's plane, a       */
                               /* non-finite ray) are answered the in-order way, never by the tree.   */
-                              /* The walk reads the tree in the form that measured faster for the    */
-                              /* scene's kinds; the two values below pick one explicitly.            */
+                              /* The walk reads the binary form (it measured faster on every kind of */
+                              /* scene); the two values below pick a form explicitly.                */
     PT_ACCEL_LBVH_BINARY = 2, /* PT_ACCEL_LBVH walked as built: 64-byte nodes, two child boxes each  */
     PT_ACCEL_LBVH_WIDE = 3    /* PT_ACCEL_LBVH with every second level folded away: 128-byte nodes,  */
                               /* four child boxes each, half the dependent node fetches per search   */
@@ -105,8 +105,9 @@ enum PtPipeline {
 
 /* How the fused scheduler hands pixels to lanes.  The image is the same either way. */
 enum PtSchedule {
-    PT_SCHEDULE_AUTO   = 0, /* the measured best: WALK for triangles in the LBVH, TILES for spheres in the LBVH and for
-                             * short lists, REFILL for other trees and for lists of more than 16 objects          */
+    PT_SCHEDULE_AUTO   = 0, /* the measured best: WALK for triangles and for 64 or more spheres in the LBVH, TILES
+                             * for other worlds in the LBVH and for short lists, REFILL for reference BVHs walked as
+                             * they are and for lists of more than 16 objects                                   */
     PT_SCHEDULE_TILES  = 1, /* one 8x8 tile per wave, one pixel per lane                                 */
     PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter                */
     PT_SCHEDULE_WALK   = 3  /* REFILL, and the wave shares the closest-hit search one tree step at a time:

@@ -622,6 +622,60 @@ def test_signature_walk_division_range_edges(oracle):
     assert same.all()
 
 
+def test_signature_shading_range_edges(oracle):
+    """The rectangle-scene kernels shade with shortened divisions and square roots while direction,
+    hit point and pdf value lie in stated ranges, and with the full operations otherwise; tables are
+    only built for scenes whose constants keep the numerators away from zero.  Scenes on either side
+    of each of those lines must give the oracle's frame."""
+    from tests._desc_tools import OwnedDesc
+    base = pt.builtin_scene("cornell", 1.0)
+
+    def scaled(factor):
+        g = OwnedDesc(base)
+        for sh in g.lists["shapes"]:
+            for k in range(6):
+                sh.p[k] *= factor
+        for x in g.lists["xforms"]:
+            if x.type == abi.XFORM_TRANSLATE:
+                for k in range(3):
+                    x.v[k] *= factor
+        for k in range(12):
+            g.camera[k] *= factor
+        return g
+
+    def check(g, signature, what, nx=48, ny=48, ns=24):
+        g.finalize()
+        sc = pt.Scene(g)
+        for schedule in (abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
+            img = sc.render(nx, ny, ns, schedule=schedule)
+            assert sc.stats().signature_walk == signature, what
+            assert_bit_exact(img, oracle.render(g, nx, ny, ns), what)
+        return sc
+
+    # directions towards the light beyond 2^20: those lanes divide in full, the cosine-sampled ones do not
+    check(scaled(4096.0), 1, "scene scaled by 4096")
+    check(scaled(2.0 ** 18), 1, "scene scaled by 2^18")
+    # a small room: directions towards the light below the table's usual size, all in range
+    check(scaled(1.0 / 64), 1, "scene scaled by 1/64")
+    # a lamp so large that the light's pdf value leaves the denominator's range
+    g = OwnedDesc(base)
+    lamp = g.lists["shapes"][g.lists["lights"][0]]
+    lamp.p[0], lamp.p[1], lamp.p[2], lamp.p[3] = -2.0 ** 27, 2.0 ** 27, -2.0 ** 27, 2.0 ** 27
+    check(g, 1, "lamp of 2^28 by 2^28")
+    # constants the table does not take: the scene then runs on the generic kernel
+    g = OwnedDesc(base)
+    g.lists["textures"][0].color[1] = 1e-9
+    check(g, 0, "a colour component below 2^-20")
+    g = OwnedDesc(base)
+    rot = [x for x in g.lists["xforms"] if x.type == abi.XFORM_ROTATE_Y][0]
+    rot.v[0], rot.v[1] = 1e-8, 1.0                               # sin, cos of a turn by 1e-8 rad
+    check(g, 0, "a box turned by 1e-8 rad")
+    g = OwnedDesc(base)
+    lamp = g.lists["shapes"][g.lists["lights"][0]]
+    lamp.p[4] = 2.0 ** 59
+    check(g, 0, "lamp beyond the constants' bound")
+
+
 @pytest.mark.parametrize("which", ["random", "cornell_spheres", "trimesh", "trimesh_big"])
 def test_shared_walk_schedule_bit_exact(oracle, which):
     """PT_SCHEDULE_WALK: the wave shares the tree search one step at a time and lanes whose search has
