@@ -496,6 +496,17 @@ __device__ __forceinline__ bool leaf_t(const SceneView& sv, int index, const Ray
         if (nx > 0) r = to_local(sv, (int)a.w, nx, ray);
     }
     face = 0;
+    if constexpr ((F & F_SPHERE) != 0 && (F & F_MSPHERE) != 0) {
+        // Both sphere kinds through one copy of the test (a wave whose lanes hold both kinds would run
+        // two): the moving sphere's centre is computed for every lane and selected, the values each
+        // kind tests with are its own.
+        if (type == PT_SHAPE_SPHERE || type == PT_SHAPE_MOVING_SPHERE) {
+            const bool moving = type == PT_SHAPE_MOVING_SPHERE;
+            const V3 cm = msphere_center(p, r.time);
+            const V3 c = mk(moving ? cm.x : p[0], moving ? cm.y : p[1], moving ? cm.z : p[2]);
+            return sphere_t(c, moving ? p[8] : p[3], r, tmin, tmax, t);
+        }
+    }
     if ((F & F_SPHERE) && type == PT_SHAPE_SPHERE)
         return sphere_t(mk(p[0], p[1], p[2]), p[3], r, tmin, tmax, t);
     if ((F & F_MSPHERE) && type == PT_SHAPE_MOVING_SPHERE)
