@@ -629,6 +629,7 @@ extern "C" void pt_scene_destroy(PtScene* sc)
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->bad_resume_host) (void)hipHostFree(sc->bad_resume_host);
     if (sc->wf_workspace) (void)hipFree(sc->wf_workspace);
+    if (sc->staging) (void)hipFree(sc->staging);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);
     if (sc->ev_k1) (void)hipEventDestroy(sc->ev_k1);
@@ -857,6 +858,21 @@ extern "C" int pt_render_pass(PtScene* sc, const PtRenderParams* p, void* d_accu
     return PT_OK;
 }
 
+// Device memory behind the entry points that take host buffers: one block per scene, grown when a
+// call needs more and kept until the scene is destroyed, so that a host rendering frame after frame
+// through pt_render does not pay an allocation per call.
+static void* scene_staging(PtScene* sc, size_t bytes)
+{
+    if (sc->staging_bytes >= bytes) return sc->staging;
+    if (sc->staging) { (void)hipFree(sc->staging); sc->staging = nullptr; sc->staging_bytes = 0; }
+    void* d = nullptr;
+    if (!hip_ok(hipMalloc(&d, bytes), "hipMalloc(staging)")) return nullptr;
+    sc->staging = d;
+    sc->staging_bytes = bytes;
+    return d;
+}
+static size_t aligned256(size_t n) { return (n + 255) & ~(size_t)255; }
+
 extern "C" int pt_render_progressive(PtScene* sc, const PtRenderParams* p, float* out_rgb, int32_t pass_samples,
                                      PtProgressFn progress, void* user)
 {
@@ -864,9 +880,9 @@ extern "C" int pt_render_progressive(PtScene* sc, const PtRenderParams* p, float
     if (p->nx <= 0 || p->ny <= 0 || p->ns <= 0) { pt::set_error("render: nx, ny, ns must be positive"); return PT_ERR_INVALID; }
     if (pass_samples <= 0) { pt::set_error("pt_render_progressive: pass_samples must be positive"); return PT_ERR_INVALID; }
     const size_t bytes = (size_t)3 * p->nx * p->ny * sizeof(float);
-    void *d_out = nullptr, *d_acc = nullptr;
-    if (!hip_ok(hipMalloc(&d_out, bytes), "hipMalloc(frame)")) return PT_ERR_OOM;
-    if (!hip_ok(hipMalloc(&d_acc, pt_accum_bytes(p->nx, p->ny)), "hipMalloc(accumulators)")) { (void)hipFree(d_out); return PT_ERR_OOM; }
+    char* block = static_cast<char*>(scene_staging(sc, aligned256(bytes) + pt_accum_bytes(p->nx, p->ny)));
+    if (!block) return PT_ERR_OOM;
+    void *d_out = block, *d_acc = block + aligned256(bytes);
     int rc = PT_OK;
     bool cancelled = false;
     for (int32_t first = 0; first < p->ns && rc == PT_OK && !cancelled; first += pass_samples) {
@@ -878,8 +894,6 @@ extern "C" int pt_render_progressive(PtScene* sc, const PtRenderParams* p, float
     }
     // a cancelled render still hands back the estimate of the samples it finished
     if (rc == PT_OK && !hip_ok(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy(frame)")) rc = PT_ERR_HIP;
-    (void)hipFree(d_out);
-    (void)hipFree(d_acc);
     if (rc == PT_OK && cancelled) { pt::set_error("pt_render_progressive: cancelled by the progress callback"); return PT_ERR_CANCELLED; }
     return rc;
 }
@@ -889,12 +903,11 @@ extern "C" int pt_render(PtScene* sc, const PtRenderParams* p, float* out_rgb)
     if (!sc || !p || !out_rgb) { pt::set_error("pt_render: null argument"); return PT_ERR_INVALID; }
     if (p->nx <= 0 || p->ny <= 0) { pt::set_error("render: nx, ny must be positive"); return PT_ERR_INVALID; }
     const size_t bytes = (size_t)3 * p->nx * p->ny * sizeof(float);
-    void* d_out = nullptr;
-    if (!hip_ok(hipMalloc(&d_out, bytes), "hipMalloc(frame)")) return PT_ERR_OOM;
+    void* d_out = scene_staging(sc, bytes);
+    if (!d_out) return PT_ERR_OOM;
     int rc = pt_render_device(sc, p, d_out, nullptr);
     if (rc == PT_OK && !hip_ok(hipStreamSynchronize(nullptr), "render (synchronize)")) rc = PT_ERR_HIP;
     if (rc == PT_OK && !hip_ok(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy(frame)")) rc = PT_ERR_HIP;
-    (void)hipFree(d_out);
     return rc;
 }
 
@@ -960,11 +973,13 @@ extern "C" int pt_trace_closest(PtScene* sc, const PtRay* rays, size_t n, int32_
 {
     if (!sc || (n && (!rays || !prim_id || !t))) { pt::set_error("pt_trace_closest: null argument"); return PT_ERR_INVALID; }
     if (n == 0) return PT_OK;
-    PtRay* d_rays = nullptr; int32_t* d_ids = nullptr; float* d_t = nullptr;
+    const size_t rays_bytes = aligned256(n * sizeof(PtRay)), ids_bytes = aligned256(n * sizeof(int32_t));
+    char* block = static_cast<char*>(scene_staging(sc, rays_bytes + ids_bytes + n * sizeof(float)));
+    if (!block) return PT_ERR_OOM;
+    PtRay* d_rays = reinterpret_cast<PtRay*>(block);
+    int32_t* d_ids = reinterpret_cast<int32_t*>(block + rays_bytes);
+    float* d_t = reinterpret_cast<float*>(block + rays_bytes + ids_bytes);
     int rc = PT_OK;
-    if (!hip_ok(hipMalloc((void**)&d_rays, n * sizeof(PtRay)), "hipMalloc(rays)") ||
-        !hip_ok(hipMalloc((void**)&d_ids, n * sizeof(int32_t)), "hipMalloc(ids)") ||
-        !hip_ok(hipMalloc((void**)&d_t, n * sizeof(float)), "hipMalloc(t)")) rc = PT_ERR_OOM;
     if (rc == PT_OK && !hip_ok(hipMemcpy(d_rays, rays, n * sizeof(PtRay), hipMemcpyHostToDevice), "hipMemcpy(rays)")) rc = PT_ERR_HIP;
     if (rc == PT_OK) {
         int variant = sc->variant;                      // the same rule as launch_variant, in waves of rays
@@ -974,9 +989,6 @@ extern "C" int pt_trace_closest(PtScene* sc, const PtRay* rays, size_t n, int32_
     }
     if (rc == PT_OK && (!hip_ok(hipMemcpy(prim_id, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy(ids)") ||
                         !hip_ok(hipMemcpy(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(t)"))) rc = PT_ERR_HIP;
-    if (d_rays) (void)hipFree(d_rays);
-    if (d_ids) (void)hipFree(d_ids);
-    if (d_t) (void)hipFree(d_t);
     return rc;
 }
 

@@ -81,6 +81,8 @@ struct PtScene {
     int* bad_resume_host = nullptr;     // pinned host word a progressive pass raises when its accumulator is not at first_sample
     int* bad_resume_dev = nullptr;      // the same word as the device sees it
     void* wf_workspace = nullptr;       // staged scheduler: lane records and queues, kept between calls
+    void* staging = nullptr;            // device side of the host-buffer entry points (pt_render, pt_trace_closest, ...), kept between calls
+    size_t staging_bytes = 0;
     size_t wf_workspace_bytes = 0;
     // timing of the most recent render
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;

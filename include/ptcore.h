@@ -257,7 +257,9 @@ void pt_scene_destroy(PtScene* scene);
 
 /* Replaces render_kernel launch + cudaMemcpy (src/ptMain.cu:612-649).  out_rgb is a host
  * buffer of nx*ny*3 floats: averaged, sqrt-gamma'd colour exactly as render_pixel returns
- * it (src/ptMain.cu:153-169), pixel index (ny-y-1)*nx+x.  Blocking. */
+ * it (src/ptMain.cu:153-169), pixel index (ny-y-1)*nx+x.  Blocking.  The device frame behind
+ * this call (and behind pt_render_progressive and pt_trace_closest) belongs to the scene: it is
+ * allocated on first use, grown when a call needs more, and freed by pt_scene_destroy. */
 int  pt_render(PtScene* scene, const PtRenderParams* params, float* out_rgb);
 
 /* Same, but d_out_rgb is device memory on the scene's device and the work is queued on
