@@ -13,15 +13,16 @@ namespace pt {
 // the root link (>= 0 node index, < 0 ~shape).  Returns a PtError.
 // d_wide (may be null): receives the same tree folded to four children per node (128-byte LbvhNode4,
 // indexed like the binary nodes; the slots of folded-away nodes stay unused).  depth (may be null):
-// levels of internal nodes of the binary tree.
+// levels of internal nodes of the binary tree.  area_sweep: worlds of up to 32 768 leaves take the
+// shape of their tree from a surface-area sweep on the host instead of the Morton order.
 int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,
-               void** d_nodes, int* n_nodes, int* root, void** d_wide, int* depth);
+               void** d_nodes, int* n_nodes, int* root, void** d_wide, int* depth, bool area_sweep);
 
 // The same tree over an explicit list of n >= 2 leaves (PT_OBJ_SHAPE entries in any order; the
 // caller supplies the tie order the walk needs).  time0 / time1: the shutter interval moving
 // spheres are bounded over (PtSceneDesc::camera[21], [22]).
 int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, const PtShape* d_shapes, const PtXform* d_xforms,
-                      void** d_nodes, int* n_nodes, int* root, void** d_wide, int* depth);
+                      void** d_nodes, int* n_nodes, int* root, void** d_wide, int* depth, bool area_sweep);
 
 }  // namespace pt
 

@@ -1,6 +1,8 @@
 // LBVH construction on the device: leaf boxes -> 30-bit Morton codes -> stable LSD radix sort
 // (wave64 ballot ranking) -> Karras radix tree -> bottom-up box fitting -> 64-byte nodes that
-// hold both children's boxes, so one node fetch decides both descents.
+// hold both children's boxes, so one node fetch decides both descents.  Worlds of up to 32 768
+// leaves take the shape of their tree from a surface-area sweep on the host instead of the
+// Morton order (sah_build); fitting and node emission are the same kernels.
 //
 // The reference builds its BVH on the host with a random-axis median split around a Lomuto
 // quicksort (src/ptBVH.cu:15-43, src/ptQuickSort.cu:19-81), quadratic on sorted or tied keys.
@@ -8,8 +10,11 @@
 // and tie rules, so any conservative tree gives the same answer.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdint>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -267,6 +272,85 @@ __global__ void k_emit_wide(const int* left, const int* right, const int* depth,
     nodes[i] = nd;
 }
 
+// ---- surface-area-heuristic tree for small worlds (host) -----------------------------------------------
+// The Morton tree splits space in the middle whatever lies in it; for a few thousand leaves a full
+// sweep over the three axes is affordable on the host and gives a tree with fewer box tests per ray
+// (random_scene: 14 node visits per search instead of 16).  Top-down: at every node the leaves are
+// ordered by box centre along each axis in turn and cut where area(left) * count(left) +
+// area(right) * count(right) is smallest.  Internal nodes are numbered in pre-order, so node 0 is the
+// root, as the walk expects; leaves are referred to as ~(position in the caller's leaf list).  Only
+// the tree's shape comes from here: boxes are fitted, and nodes emitted, by the kernels above.
+constexpr int SAH_MAX_LEAVES = 32768;
+constexpr int SAH_MAX_DEPTH = 56;                      // the walks' stacks hold 64 entries
+
+struct HostTree { std::vector<int> left, right, parent; int depth = 0; };
+
+double half_area(const Box& b)
+{
+    const double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2];
+    const double a = dx * dy + dy * dz + dz * dx;
+    return std::isfinite(a) ? a : 1e300;
+}
+Box join(const Box& a, const Box& b)
+{
+    Box u;
+    for (int k = 0; k < 3; k++) { u.mn[k] = std::fmin(a.mn[k], b.mn[k]); u.mx[k] = std::fmax(a.mx[k], b.mx[k]); }
+    return u;
+}
+
+// Builds the subtree over ids[begin, end) (reordered in place) and returns its link.
+int sah_subtree(const std::vector<Box>& boxes, std::vector<int>& ids, int begin, int end, int parent, int level, HostTree& t,
+                std::vector<int>& order, std::vector<double>& from_right)
+{
+    const int n = end - begin;
+    if (n == 1) return ~ids[(size_t)begin];
+    const int node = (int)t.left.size();
+    t.left.push_back(0); t.right.push_back(0); t.parent.push_back(parent);
+    t.depth = std::max(t.depth, level + 1);
+    int best_axis = -1, best_cut = n / 2;
+    double best_cost = 0;
+    if (n > 2 && level < SAH_MAX_DEPTH - 16) {                // deeper than that (degenerate input): halve, 15 more levels at most
+        for (int axis = 0; axis < 3; axis++) {
+            order.assign(ids.begin() + begin, ids.begin() + end);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                return (double)boxes[(size_t)a].mn[axis] + boxes[(size_t)a].mx[axis] < (double)boxes[(size_t)b].mn[axis] + boxes[(size_t)b].mx[axis];
+            });
+            Box acc = boxes[(size_t)order[(size_t)n - 1]];
+            from_right[(size_t)n - 1] = half_area(acc);
+            for (int i = n - 2; i >= 1; i--) { acc = join(acc, boxes[(size_t)order[(size_t)i]]); from_right[(size_t)i] = half_area(acc); }
+            acc = boxes[(size_t)order[0]];
+            for (int cut = 1; cut < n; cut++) {                // `cut` leaves go left
+                const double cost = half_area(acc) * cut + from_right[(size_t)cut] * (n - cut);
+                const bool nearer_the_middle = std::abs(2 * cut - n) < std::abs(2 * best_cut - n);
+                if (best_axis < 0 || cost < best_cost || (cost == best_cost && nearer_the_middle)) { best_cost = cost; best_axis = axis; best_cut = cut; }
+                acc = join(acc, boxes[(size_t)order[(size_t)cut]]);
+            }
+        }
+    } else {
+        best_axis = level % 3; best_cut = n / 2;
+    }
+    std::stable_sort(ids.begin() + begin, ids.begin() + end, [&](int a, int b) {
+        return (double)boxes[(size_t)a].mn[best_axis] + boxes[(size_t)a].mx[best_axis] < (double)boxes[(size_t)b].mn[best_axis] + boxes[(size_t)b].mx[best_axis];
+    });
+    const int l = sah_subtree(boxes, ids, begin, begin + best_cut, node, level + 1, t, order, from_right);
+    const int r = sah_subtree(boxes, ids, begin + best_cut, end, node, level + 1, t, order, from_right);
+    t.left[(size_t)node] = l; t.right[(size_t)node] = r;
+    return node;
+}
+
+bool sah_build(const std::vector<Box>& boxes, HostTree& t)
+{
+    const int n = (int)boxes.size();
+    for (const Box& b : boxes)
+        for (int k = 0; k < 3; k++) if (!(b.mn[k] <= b.mx[k])) return false;      // NaN or inverted: leave it to the Morton tree
+    std::vector<int> ids((size_t)n), order;
+    std::iota(ids.begin(), ids.end(), 0);
+    std::vector<double> from_right((size_t)n);
+    t.left.reserve((size_t)n); t.right.reserve((size_t)n); t.parent.reserve((size_t)n);
+    sah_subtree(boxes, ids, 0, n, -1, 0, t, order, from_right);
+    return (int)t.left.size() == n - 1 && t.depth <= SAH_MAX_DEPTH;
+}
+
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -287,7 +371,7 @@ int hip_fail(hipError_t e, const char* what)
 namespace pt {
 
 int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,
-               void** d_nodes_out, int* n_nodes_out, int* root_out, void** d_wide_out, int* depth_out)
+               void** d_nodes_out, int* n_nodes_out, int* root_out, void** d_wide_out, int* depth_out, bool area_sweep)
 {
     const int n = desc->n_world;
     *d_nodes_out = nullptr; *n_nodes_out = 0; *root_out = 0;
@@ -299,11 +383,11 @@ int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* 
         }
     }
     return lbvh_build_leaves(desc->world, n, desc->camera[21], desc->camera[22], d_shapes, d_xforms, d_nodes_out, n_nodes_out, root_out,
-                             d_wide_out, depth_out);
+                             d_wide_out, depth_out, area_sweep);
 }
 
 int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, const PtShape* d_shapes, const PtXform* d_xforms,
-                      void** d_nodes_out, int* n_nodes_out, int* root_out, void** d_wide_out, int* depth_out)
+                      void** d_nodes_out, int* n_nodes_out, int* root_out, void** d_wide_out, int* depth_out, bool area_sweep)
 {
     *d_nodes_out = nullptr; *n_nodes_out = 0; *root_out = 0;
     if (d_wide_out) *d_wide_out = nullptr;
@@ -330,18 +414,38 @@ int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, c
     const int B = 256, G = (n + B - 1) / B, GI = (n_int + B - 1) / B;
     hipLaunchKernelGGL(k_leaf_boxes, dim3(G), dim3(B), 0, nullptr, d_shapes, d_xforms, world.as<PtObject>(), n,
                        time0, time1, boxes.as<Box>(), cb.as<unsigned>());
-    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, nullptr, boxes.as<Box>(), n, cb.as<unsigned>(), keys_a.as<uint64_t>());
-    // the low 32 key bits (leaf number) are already ascending: four stable passes over the Morton bits
     uint64_t* src = keys_a.as<uint64_t>();
-    uint64_t* dst = keys_b.as<uint64_t>();
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 32 + 8 * pass;
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(64), 0, nullptr, src, n, shift, hist.as<unsigned>(), n_tiles);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, hist.as<unsigned>(), 256 * n_tiles);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(64), 0, nullptr, src, dst, n, shift, hist.as<unsigned>(), n_tiles);
-        uint64_t* tmp = src; src = dst; dst = tmp;
+    bool by_area = false;
+#ifndef PT_LBVH_MORTON_ONLY
+    if (area_sweep && n <= SAH_MAX_LEAVES) {
+        // small world: the tree's shape from the host's surface-area sweep over the boxes just computed
+        std::vector<Box> h_boxes((size_t)n);
+        if ((e = hipMemcpy(h_boxes.data(), boxes.p, (size_t)n * sizeof(Box), hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "read leaf boxes");
+        HostTree t;
+        if (sah_build(h_boxes, t)) {
+            std::vector<uint64_t> identity((size_t)n);                 // leaf j of the tree is leaf j of the caller's list
+            for (int j = 0; j < n; j++) identity[(size_t)j] = (uint64_t)j;
+            if ((e = hipMemcpy(src, identity.data(), (size_t)n * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(left.p, t.left.data(), (size_t)n_int * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(right.p, t.right.data(), (size_t)n_int * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(parent.p, t.parent.data(), (size_t)n_int * 4, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "copy tree");
+            by_area = true;
+        }
     }
-    hipLaunchKernelGGL(k_karras, dim3(GI), dim3(B), 0, nullptr, src, n, left.as<int>(), right.as<int>(), parent.as<int>());
+#endif
+    if (!by_area) {
+        hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, nullptr, boxes.as<Box>(), n, cb.as<unsigned>(), keys_a.as<uint64_t>());
+        // the low 32 key bits (leaf number) are already ascending: four stable passes over the Morton bits
+        uint64_t* dst = keys_b.as<uint64_t>();
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 32 + 8 * pass;
+            hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(64), 0, nullptr, src, n, shift, hist.as<unsigned>(), n_tiles);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, nullptr, hist.as<unsigned>(), 256 * n_tiles);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(64), 0, nullptr, src, dst, n, shift, hist.as<unsigned>(), n_tiles);
+            uint64_t* tmp = src; src = dst; dst = tmp;
+        }
+        hipLaunchKernelGGL(k_karras, dim3(GI), dim3(B), 0, nullptr, src, n, left.as<int>(), right.as<int>(), parent.as<int>());
+    }
     if ((e = hipMemset(ready.p, 0, (size_t)n_int * 4)) != hipSuccess) return hip_fail(e, "memset ready");
     bool fitted = false;
     for (int sweep = 0; sweep < 80 && !fitted; sweep++) {

@@ -101,6 +101,54 @@ def test_lbvh_exact_ties_follow_list_order(oracle):
     np.testing.assert_array_equal(bits(t_g), bits(t_o))
 
 
+def test_tree_over_degenerate_worlds(oracle):
+    """Worlds that give a tree builder nothing to split on: every sphere in the same place (all
+    cuts cost the same), spheres strung along one axis in list order, and one sphere enclosing all
+    others.  The tree must stay within the walks' stack whatever its shape, and the answers are the
+    list walk's (the earliest of coincident spheres keeps a tie)."""
+    from tests._desc_tools import OwnedDesc
+    base = pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)
+    rng = np.random.default_rng(3)
+    rays = random_rays(rng, 30000, -12, 12)
+    aimed = rays[:10000]                                       # a third of them towards the place the first world piles its spheres on
+    aimed["d"] = (np.array([1.0, 0.5, -2.0], np.float32) + rng.normal(size=(10000, 3)).astype(np.float32) * 0.5) - aimed["o"]
+
+    def world(edit):
+        g = OwnedDesc(base)
+        for k, o in enumerate(g.lists["world"]):
+            sh = g.lists["shapes"][o.index]
+            if sh.type != abi.SHAPE_SPHERE:
+                sh.type = abi.SHAPE_SPHERE                     # plain spheres only: centre p[0..2], radius p[3]
+            edit(k, sh)
+        g.scalars["accel"] = abi.ACCEL_LBVH
+        g.finalize()
+        return g
+
+    def same_place(k, sh):
+        sh.p[0], sh.p[1], sh.p[2], sh.p[3] = 1.0, 0.5, -2.0, 0.75
+
+    def on_a_line(k, sh):
+        sh.p[0], sh.p[1], sh.p[2], sh.p[3] = 0.05 * k - 12.0, 0.2, 0.0, 0.2
+
+    def one_around_all(k, sh):
+        if k == 0:
+            sh.p[0], sh.p[1], sh.p[2], sh.p[3] = 0.0, 0.0, 0.0, 1000.0
+
+    for edit in (same_place, on_a_line, one_around_all):
+        g = world(edit)
+        sc = pt.Scene(g)
+        assert len(sc.lbvh_nodes()) == g.c.n_world - 1
+        ids_o, t_o = oracle.trace_closest(g, rays)
+        for accel in (abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
+            g.c.accel = accel
+            ids_g, t_g = pt.Scene(g).trace_closest(rays)
+            np.testing.assert_array_equal(ids_g, ids_o)
+            np.testing.assert_array_equal(bits(t_g), bits(t_o))
+        assert (ids_o != abi.ID_MISS).sum() > 100
+        if edit is same_place:
+            assert set(np.unique(ids_o)) <= {abi.ID_MISS, g.lists["world"][0].index}
+
+
 @pytest.mark.parametrize("accel", [abi.ACCEL_LIST, abi.ACCEL_LBVH])
 def test_triangle_mesh_bit_exact(oracle, accel):
     d = pt.trimesh_scene(12, 1.0)                             # 288 triangles inside the Cornell walls

@@ -1,6 +1,6 @@
 // Issue-rate probe for gfx950 vector instructions: cycles per wave-instruction on one SIMD at 1, 2,
-// 4 and 8 resident waves per SIMD.  Development tool (not part of the library); results are quoted
-// in the design notes.   hipcc -O2 --offload-arch=gfx950 -o valu_probe valu_probe.hip
+// 4 and 8 resident waves per SIMD.  Development tool (not part of the library).
+//   hipcc -O2 --offload-arch=gfx950 -o valu_probe valu_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
