@@ -9,6 +9,10 @@ mkdir -p $O
 T="timeout -k 10"
 stats_csv() { find "$1" -name '*kernel_stats.csv' | head -1; }
 
+echo "== counters of the headline kernel (bench.py quotes their HBM traffic while the stamp matches the library)"
+$T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_tiles -- python3 bench.py --steps 1 --warmup 0 --spp 512 --no-cpu-baseline > $O/pmc_cornell.log
+cp $O/pmc_cornell/summary.json $O/pmc_cornell1024x512_k_render_tiles.json
+mkdir -p profiles/$R && cp $O/pmc_cornell1024x512_k_render_tiles.json profiles/$R/
 echo "== bench.py default"
 $T 600 python3 bench.py > $O/bench_cornell1024x4096_default.json
 cat $O/bench_cornell1024x4096_default.json
@@ -20,8 +24,6 @@ $T 600 python3 bench/configs.py > $O/configs_1gpu.jsonl
 $T 600 rocprofv3 --kernel-trace --stats -d $O/prof_configs --output-format csv -- python3 bench/configs.py > $O/configs_1gpu_under_rocprof.jsonl
 cp "$(stats_csv $O/prof_configs)" $O/configs_1gpu_kernel_stats.csv
 echo "== counters"
-$T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_tiles -- python3 bench.py --steps 1 --warmup 0 --spp 512 --no-cpu-baseline > $O/pmc_cornell.log
-cp $O/pmc_cornell/summary.json $O/pmc_cornell1024x512_k_render_tiles.json
 $T 900 python3 tools/pmc_collect.py $O/pmc_shard k_render_tiles -- python3 tools/shard_render.py 8 512 > $O/pmc_shard.log
 cp $O/pmc_shard/summary.json $O/pmc_cornell_eighth_shard.json
 $T 900 python3 tools/pmc_collect.py $O/pmc_c1 k_render_walk -- python3 bench/configs.py --only c1 --quick > $O/pmc_c1.log
