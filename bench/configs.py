@@ -92,7 +92,7 @@ def main():
                        pt.builtin_scene("final", 16 / 9, earth_rgb=synthetic_earthmap(), accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, model="final_lbvh", **kw))
     if a.only in ("", "c3noearth"):
         res.append(run("C3 final 1920x1080 without the earth sphere (the reference's device branch), LBVH",
-                       pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, **kw))
+                       pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH), 1920, 1080, 256 // q, model="final_lbvh_no_earth", **kw))
     if a.only in ("", "c4"):
         d = pt.trimesh_scene(a.grid, 16 / 9)
         d.c.accel = abi.ACCEL_LBVH

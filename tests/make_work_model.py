@@ -66,6 +66,9 @@ def tree_configs():
     prefix = next(i for i in range(d.c.n_world) if d.c.world[i].type == abi.OBJ_MEDIUM)
     out.append(("final_lbvh", d, prefix, 1, 0, 320, 180, 8, "BASELINE configs[3] as the product runs it: RTNW final with a 512x256 earth map; the 400 boxes of the "
                 "reference BVH and the shapes before the first medium in the library's LBVH, the media and what follows walked in order"))
+    d = pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH_BINARY)
+    prefix = next(i for i in range(d.c.n_world) if d.c.world[i].type == abi.OBJ_MEDIUM)
+    out.append(("final_lbvh_no_earth", d, prefix, 1, 0, 320, 180, 8, "RTNW final as the reference's device branch builds it (no earth sphere), through the library's LBVH"))
     d = pt.trimesh_scene(1000, 16 / 9)
     d.c.accel = abi.ACCEL_LBVH_BINARY
     out.append(("trimesh_lbvh", d, d.c.n_world, 0, 1, 480, 270, 1, "BASELINE configs[4]: 2 000 000 triangles + Cornell enclosure in the library's LBVH "
@@ -98,7 +101,7 @@ def main():
             out["configs"][key] = entry(c, note, "%dx%d at %d spp, depth 25" % (nx, ny, ns))
             print(key, json.dumps(out["configs"][key]), flush=True)
     else:
-        for key in ("random_lbvh", "final_lbvh", "trimesh_lbvh"):
+        for key in ("random_lbvh", "final_lbvh", "final_lbvh_no_earth", "trimesh_lbvh"):
             if key in old:
                 out["configs"][key] = old[key]
                 print(key, "(kept: no GPU to build the tree on)", flush=True)
