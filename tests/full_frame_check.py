@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--trimesh", type=int, default=0, help="the height field of 2*N*N triangles in the Cornell room instead of --scene")
     ap.add_argument("--wavefront", action="store_true", help="the staged scheduler instead of the fused one")
     ap.add_argument("--lbvh", action="store_true", help="the GPU walks the library's tree; the oracle always walks the list")
+    ap.add_argument("--earthmap", action="store_true", help="the final scene with the synthetic 512x256 earth map on its tenth object")
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--shards", type=int, default=32)
     ap.add_argument("--threads", type=int, default=16)
@@ -36,7 +37,14 @@ def main():
     oracle = _oracle.load()
     pt.set_device(0)
     nx, ny = a.size, (a.ny or a.size)
-    d = pt.trimesh_scene(a.trimesh, nx / ny) if a.trimesh else pt.builtin_scene(a.scene, nx / ny)
+    if a.trimesh:
+        d = pt.trimesh_scene(a.trimesh, nx / ny)
+    elif a.earthmap:
+        sys.path.insert(0, os.path.join(ROOT, "bench"))
+        import configs as bench_configs
+        d = pt.builtin_scene(a.scene, nx / ny, earth_rgb=bench_configs.synthetic_earthmap())
+    else:
+        d = pt.builtin_scene(a.scene, nx / ny)
     if a.lbvh:
         d.c.accel = pt.abi.ACCEL_LBVH
     sc = pt.Scene(d)
@@ -52,7 +60,7 @@ def main():
         print("oracle shard %d/%d, %.0f s" % (k + 1, a.shards, time.perf_counter() - t0), flush=True)
     cpu_s = time.perf_counter() - t0
     same = gpu.view(np.uint32) == cpu.view(np.uint32)
-    res = {"scene": ("trimesh %d" % a.trimesh) if a.trimesh else a.scene, "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "values": int(same.size), "values_different": int((~same).sum()),
+    res = {"scene": ("trimesh %d" % a.trimesh) if a.trimesh else a.scene + (" + synthetic earth map" if a.earthmap else ""), "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "values": int(same.size), "values_different": int((~same).sum()),
            "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": nx * ny * a.spp / cpu_s / 1e6,
            "gpu_kernel_ms": sc.stats().kernel_ms, "frame_mean": float(gpu.mean())}
     print(json.dumps(res), flush=True)
