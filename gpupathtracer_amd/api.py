@@ -191,7 +191,8 @@ def libm_eval(fn, x, on_device):
     """fn: 0 sin, 1 cos, 2 log, 3 x**5, 4/5 sine/cosine of the combined evaluation, 6 asin, 7 atan2
     (x then holds (y, x) pairs, shape (n, 2)) -- the library's libm replacements on float32 inputs;
     8/9 the kernels' in-range square root and sqrtf, 10/11 their in-range quotient and n / d on (n, d)
-    pairs (on the host all four are the plain operation)."""
+    pairs (on the host all four are the plain operation); 12/13 sine/cosine of the combined evaluation in its
+    form for arguments in [0, 120)."""
     x = np.ascontiguousarray(x, np.float32)
     pairs = int(fn) in (7, 10, 11)
     n = x.size // 2 if pairs else x.size

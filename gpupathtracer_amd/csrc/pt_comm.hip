@@ -43,6 +43,7 @@ __global__ void k_libm_eval(int fn, const float* __restrict__ x, size_t n, float
     case 6: r = ptm::asinf_glibc(v); break;
     case 8: r = ptd::sqrt_tame(v); break;
     case 9: r = sqrtf(v); break;
+    case 12: case 13: { float sn, cs; ptm::sincosf_glibc<true>(v, &sn, &cs); r = fn == 12 ? sn : cs; } break;   // the form for 0 <= v < 120
     default: { float sn, cs; ptm::sincosf_glibc(v, &sn, &cs); r = fn == 4 ? sn : cs; } break;
     }
     out[i] = r;
@@ -164,7 +165,7 @@ extern "C" void pt_comm_destroy(PtComm* c)
 
 extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device)
 {
-    if (fn < 0 || fn > 11 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
+    if (fn < 0 || fn > 13 || (n && (!x || !out))) { pt::set_error("pt_libm_eval: bad arguments"); return PT_ERR_INVALID; }
     if (n == 0) return PT_OK;
     if (!on_device) {
         for (size_t i = 0; i < n; i++) {
@@ -177,6 +178,7 @@ extern "C" int pt_libm_eval(int fn, const float* x, size_t n, float* out, int on
             case 7: out[i] = ptm::atan2f_glibc(x[2 * i], x[2 * i + 1]); break;
             case 8: case 9: out[i] = std::sqrt(x[i]); break;
             case 10: case 11: out[i] = x[2 * i] / x[2 * i + 1]; break;
+            case 12: case 13: { float sn, cs; ptm::sincosf_glibc<true>(x[i], &sn, &cs); out[i] = fn == 12 ? sn : cs; } break;
             default: { float sn, cs; ptm::sincosf_glibc(x[i], &sn, &cs); out[i] = fn == 4 ? sn : cs; } break;
             }
         }

@@ -161,7 +161,7 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Pcg& g)
     const float z = 1 - 2 * g.rand();
     const float r = sqrtf(fmaxf(0.0f, 1 - z * z));
     float sn, cs;
-    ptm::sincosf_glibc(phi, &sn, &cs);
+    ptm::sincosf_glibc<true>(phi, &sn, &cs);        // phi = 2 pi rand() < 6.3
     return mk(r * cs, r * sn, z);
 }
 __device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
@@ -169,7 +169,7 @@ __device__ __forceinline__ V3 random_in_unit_disk(Pcg& g)
     const float r = sqrtf(g.rand());
     const float theta = g.rand() * 2 * PI_F;
     float sn, cs;
-    ptm::sincosf_glibc(theta, &sn, &cs);
+    ptm::sincosf_glibc<true>(theta, &sn, &cs);      // theta = 2 pi rand() < 6.3
     return mk(r * cs, r * sn, 0.0f);
 }
 // r1, r2: results of Pcg::rand(), i.e. multiples of 2^-32 in [0, 1): both square roots take an
@@ -180,7 +180,7 @@ __device__ __forceinline__ V3 random_cosine_direction(float r1, float r2)
     float z = sqrt_tame(1 - r2);
     float phi = 2 * PI_F * r1;
     float sn, cs;
-    ptm::sincosf_glibc(phi, &sn, &cs);
+    ptm::sincosf_glibc<true>(phi, &sn, &cs);        // phi = 2 pi rand() < 6.3
     const float root = sqrt_tame(r2);
     float x = cs * 2 * root;
     float y = sn * 2 * root;
@@ -199,7 +199,7 @@ __device__ __forceinline__ V3 random_to_unit_sphere(float radius, float dist_sqr
     float z = 1 + r2 * (sqrtf(1 - radius * radius / dist_sqrd) - 1);
     float phi = 2 * PI_F * r1;
     float sn, cs;
-    ptm::sincosf_glibc(phi, &sn, &cs);
+    ptm::sincosf_glibc<true>(phi, &sn, &cs);        // phi = 2 pi rand() < 6.3
     float x = cs * sqrtf(1 - z * z);
     float y = sn * sqrtf(1 - z * z);
     return mk(x, y, z);

@@ -22,7 +22,8 @@ using namespace ptk;
 // 37.7/37.6/37.8/38.5; RTNW final 800^2 x64 through the tree at 2/3/4/5 = 35.7/31.9/36.4/37.1 and x16
 // through the reference's own BVH 22.9/19.6/21.1/21.1; random spheres 1200x800 x64 through the tree at
 // 3/4/5/6 = 31.2/27.0/25.9/25.3, x16 over the list at 1/4/5 = 49.0/45.4/43.5; 2 M triangles 3840x2160
-// x16 at 4/6 = 64.5/59.7 (a 1000-triangle mesh prefers 4: its walk is not waiting on memory).  The
+// x16 at 4/6 = 64.5/59.7 and, later, 5/6 = 55.4/55.2 with 4 instead of 27 spilled registers at 5 (taken:
+// a tenth of the scratch traffic for the same time; a 20 000-triangle mesh 41.2/42.4).  The
 // tree kernels keep 24 KB of stack in LDS per workgroup, so no more than 6 fit a CU whatever is asked.
 __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 {
@@ -30,7 +31,7 @@ __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
     return PT_EXP_BLOCKS;
 #endif
     const uint32_t G = F & ~F_LBVH4;                       // the form of the tree does not change the table
-    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 6 : 1;
+    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 5 : 1;
 }
 
 // Signature worlds shade from the face table (shade_sig): every workgroup keeps a copy in LDS, 64 bytes

@@ -158,6 +158,9 @@ PT_HD float cosf_glibc(float y)
 // (round-to-nearest is symmetric), so no lane evaluates a polynomial twice and a wave whose lanes
 // sit in different quadrants does not diverge.  Below pi/4 the reduction yields n = 0 and returns
 // x itself, so that range needs no branch of its own.
+// BELOW_120: the caller knows 0 <= y < 120 (an angle of 2 pi times a number below 1), so the large-argument
+// reduction and the non-finite case are not compiled in; the result is the same.
+template <bool BELOW_120 = false>
 PT_HD void sincosf_glibc(float y, float* sp, float* cp)
 {
     double x = y;
@@ -166,7 +169,7 @@ PT_HD void sincosf_glibc(float y, float* sp, float* cp)
         *sp = y; *cp = 1.0f;
         return;
     }
-    if (abstop12(y) < abstop12(120.0f)) {
+    if (BELOW_120 || abstop12(y) < abstop12(120.0f)) {
         x = reduce_fast(x, &n);
         q = n;
     } else if (abstop12(y) < 0x7f8) {

@@ -427,7 +427,9 @@ void pt_comm_destroy(PtComm* comm);
  * fn 8 to 11 expose the kernels' shortened arithmetic next to the compiler's full sequences, for tests
  * of the ranges the kernels use them in: 8 the square root for arguments that are +0 or at least
  * 2^-96, 9 sqrtf; 10 the quotient n / d for 2^-30 <= |d| <= 2^60 and 2^-103 <= |n| <= 2^60, 11 n / d,
- * both on n (numerator, denominator) pairs.  On the host all four are the plain operation. */
+ * both on n (numerator, denominator) pairs.  On the host all four are the plain operation.
+ * fn 12 and 13: sine and cosine from the combined evaluation in the form the direction samplers use
+ * for their angles (arguments in [0, 120) only: the large-argument reduction is left out). */
 int  pt_libm_eval(int fn, const float* x, size_t n, float* out, int on_device);
 
 #ifdef __cplusplus

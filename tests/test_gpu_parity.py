@@ -236,6 +236,12 @@ def test_device_libm_matches_glibc(oracle):
         b = oracle.libm(fn - 4 if fn >= 4 else fn, arg)
         same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (fn, arg[~same][:5], a[~same][:5], b[~same][:5])
+    # the samplers' form of the combined evaluation (angles 2 pi rand(): arguments in [0, 120))
+    ang = np.concatenate([rng.uniform(0, 6.3, 1_000_000), rng.uniform(0, 119.9, 500_000), np.float32(2 * np.pi) * (np.arange(65536) / 65536.0),
+                          np.array([0.0, 1e-45, 2.0 ** -12, 0.78539816, 6.2831845, 119.99999])]).astype(np.float32)
+    for fn in (12, 13):
+        a, b = pt.libm_eval(fn, ang, on_device=True), oracle.libm(fn - 12, ang)
+        assert (bits(a) == bits(b)).all(), fn
     # asin and atan2 of MovingSphere's uv (include/ptSphere.h:22-28)
     xs = np.concatenate([rng.uniform(-1.2, 1.2, 1_000_000), x[:1_000_000] / 130]).astype(np.float32)
     a, b = pt.libm_eval(6, xs, on_device=True), oracle.libm(6, xs)
