@@ -22,8 +22,8 @@ using namespace ptk;
 // 37.7/37.6/37.8/38.5; RTNW final 800^2 x64 through the tree at 2/3/4/5 = 35.7/31.9/36.4/37.1 and x16
 // through the reference's own BVH 22.9/19.6/21.1/21.1; random spheres 1200x800 x64 through the tree at
 // 3/4/5/6 = 31.2/27.0/25.9/25.3, x16 over the list at 1/4/5 = 49.0/45.4/43.5; 2 M triangles 3840x2160
-// x16 at 4/6 = 64.5/59.7 and, later, 5/6 = 55.4/55.2 with 4 instead of 27 spilled registers at 5 (taken:
-// a tenth of the scratch traffic for the same time; a 20 000-triangle mesh 41.2/42.4).  The
+// x16 at 4/6 = 64.5/59.7 and, later, x64 at 5/6 = 191.5/185.0 (4 against 24 spilled registers: 0.2 against 1 GB
+// of scratch written per 4 spp, which HBM has to spare there; a 20 000-triangle mesh 42.2/41.5).  The
 // tree kernels keep 24 KB of stack in LDS per workgroup, so no more than 6 fit a CU whatever is asked.
 __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 {
@@ -31,7 +31,7 @@ __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
     return PT_EXP_BLOCKS;
 #endif
     const uint32_t G = F & ~F_LBVH4;                       // the form of the tree does not change the table
-    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 5 : 1;
+    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 6 : 1;
 }
 
 // Signature worlds shade from the face table (shade_sig): every workgroup keeps a copy in LDS, 64 bytes
@@ -239,6 +239,26 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
     }
 }
 
+// The in-order list walk a ray takes when the tree cannot answer for it (a non-finite ray, a wrapped
+// rectangle's plane: see ray_may_enter_tree), out of line for worlds of plain shapes: it runs for a
+// handful of rays per frame, and inlined into the shared-walk kernel its shape dispatch costs that
+// kernel registers on every bounce.  No medium, no reference BVH: it draws no random number and needs
+// no stack.  Arguments and result by value, the scene through its copy in device memory.
+struct ListWalkHit { int any; float t; int id, face; };
+template <uint32_t F>
+__device__ __attribute__((noinline)) ListWalkHit list_walk_out_of_line(const SceneView* view, float ox, float oy, float oz,
+                                                                     float dx, float dy, float dz, float time)
+{
+    static_assert((F & (F_MEDIUM | F_REFBVH | F_LBVH | F_IMAGE)) == 0, "plain shapes, walked in order");
+    Ray r; r.o = mk(ox, oy, oz); r.d = mk(dx, dy, dz); r.time = time;
+    Hit h;
+    Pcg unused; unused.state = 0; unused.inc = 1;
+    ListWalkHit out;
+    out.any = world_hit<F, AnyWorld>(*view, r, 0.001f, FLT_MAX, h, unused, nullptr) ? 1 : 0;
+    out.t = h.t; out.id = h.id; out.face = h.face;
+    return out;
+}
+
 // Fused scheduler for worlds held in the library's LBVH: persistent lanes as in k_render_refill, and
 // the closest-hit search is shared by the wave one tree step at a time.  Lanes whose search has
 // ended wait; when WALK_WAIT_LANES of them wait (or nobody is left walking) the wave leaves the
@@ -275,8 +295,17 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray))) {     // see accepts_nan: the list, in order
                 const InPlaneHit got = lbvh_in_plane_t<F>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z, st.ray.d.x, st.ray.d.y, st.ray.d.z,
                                                           st.ray.time, 0.001f, FLT_MAX);
-                if (got.found < 0) any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
-                else {
+                if (got.found < 0) {
+                    if constexpr ((F & (F_MEDIUM | F_REFBVH | F_IMAGE)) == 0) {
+                        const ListWalkHit lw = list_walk_out_of_line<(F & ~(F_LBVH | F_LBVH4))>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z,
+                                                                                              st.ray.d.x, st.ray.d.y, st.ray.d.z, st.ray.time);
+                        any = lw.any != 0;
+                        h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX;
+                        if (any) { h.t = lw.t; h.id = lw.id; h.face = lw.face; }
+                    } else {
+                        any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+                    }
+                } else {
                     any = got.found > 0;
                     h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX;
                     if (any) { h.t = got.t; h.id = got.id; h.face = got.face; }
