@@ -633,6 +633,8 @@ extern "C" void pt_scene_destroy(PtScene* sc)
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->bad_resume_host) (void)hipHostFree(sc->bad_resume_host);
     if (sc->wf_workspace) (void)hipFree(sc->wf_workspace);
+    if (sc->wf_host) (void)hipHostFree(sc->wf_host);
+    for (hipEvent_t e : sc->wf_ev) if (e) (void)hipEventDestroy(e);
     if (sc->staging) (void)hipFree(sc->staging);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);

@@ -80,7 +80,9 @@ struct PtScene {
     unsigned* next_slot = nullptr;      // device counter of the fused scheduler's pixel-slot pool
     int* bad_resume_host = nullptr;     // pinned host word a progressive pass raises when its accumulator is not at first_sample
     int* bad_resume_dev = nullptr;      // the same word as the device sees it
-    void* wf_workspace = nullptr;       // staged scheduler: lane records and queues, kept between calls
+    void* wf_workspace = nullptr;       // staged scheduler: lane state and queues, kept between calls
+    unsigned* wf_host = nullptr;        // staged scheduler: pinned host words the finished-lane counts are copied into
+    hipEvent_t wf_ev[2] = {nullptr, nullptr};   // staged scheduler: one event per chunk of rounds in flight
     void* staging = nullptr;            // device side of the host-buffer entry points (pt_render, pt_trace_closest, ...), kept between calls
     size_t staging_bytes = 0;
     size_t wf_workspace_bytes = 0;

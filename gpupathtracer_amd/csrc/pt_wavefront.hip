@@ -2,8 +2,7 @@
 //
 // The reference traces a pixel's samples and bounces in nested loops inside one thread
 // (render_kernel / render_pixel / color, src/ptMain.cu:95-190).  Here the same per-pixel state
-// machine is cut at its divergent points and every stage runs as its own kernel over a compacted
-// queue of pixel lanes:
+// machine is cut at its divergent points and every stage runs over a compacted queue of pixel lanes:
 //
 //   extend   : world->hit for every lane with a live ray; misses and light hits end the path in
 //              place (accumulate, start the pixel's next sample), other hits are binned by
@@ -15,8 +14,20 @@
 // count, the popcount of lower lanes gives each lane its slot.  Each lane still owns one pixel and
 // carries that pixel's PCG state from sample to sample and bounce to bounce, so the image is the
 // same, bit for bit, as the fused scheduler's and the reference's.
+//
+// Lane state is held field by field (structure of arrays, 16-byte elements where a stage reads a
+// group together), so a stage moves only what it reads or changes: the search reads the ray (32
+// bytes) and writes the hit (16), the shading reads ray, hit, running product and random state and
+// writes ray, product and state.  One launch is one round of both stages, skewed by a round: the
+// search of round r fills the shade queues that round r + 1 empties, and both feed the extend queue
+// of round r + 1, so the two stages of a launch work on different lanes and nothing in a launch
+// waits for anything else in it.  Counters rotate through three sets; the set nobody reads or
+// appends to in a round is cleared by that round's first workgroup, so a round is exactly one
+// launch.  The host enqueues rounds in chunks and reads the finished-lane count of a chunk while the
+// next one is already queued.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 
 #include "pt_host.h"
@@ -28,76 +39,112 @@ namespace {
 
 // Queue kinds for the shade stage (material-sorted).
 enum : int { Q_LAMBERT = 0, Q_METAL = 1, Q_DIELECTRIC = 2, Q_ISOTROPIC = 3, N_SHADE_Q = 4 };
-// counts[]: 0,1 = extend queue of each parity, 2.. = shade queues, then [C_DONE] finished lanes
-enum : int { C_EXT0 = 0, C_EXT1 = 1, C_SHADE = 2, C_DONE = C_SHADE + N_SHADE_Q, N_COUNTS = C_DONE + 1 };
-
-// One 128-byte record per pixel lane: a lane's whole state sits in one cache line, so a stage that
-// visits lanes in queue order (scattered after compaction) still fetches whole lines.
-struct alignas(128) LaneRec {
-    uint32_t pix;         // pixel index i = ytop * nx + x
-    int32_t  sample;      // samples finished
-    int32_t  depth;       // bounces done on the current path
-    int32_t  hit_face;
-    uint64_t rng;         // PCG state (the increment is (i << 1) | 1)
-    int32_t  hit_id;
-    float    hit_t;
-    float    ray[7];      // origin, direction, time
-    int32_t  uv_id;       // stale-uv bookkeeping, read only by image textures
-    float    thr[3];      // running product (accumCol of color())
-    int32_t  uv_face;
-    float    acc[3];      // pixel sum
-    float    uv_t;
-    float    pad[8];
-};
-static_assert(sizeof(LaneRec) == 128, "one cache line per lane");
+// counts[]: three sets of the extend queue's length, three sets of the shade queues' lengths, then the
+// finished lanes and the allocated lanes.  Every counter has a 128-byte line to itself (C_STRIDE words
+// apart): an atomic on a counter is served where the line lives, one at a time -- about 22 ns each on
+// MI355X, whichever word of the line it names.
+enum : int { C_EXT = 0, C_SHADE = 3, C_DONE = C_SHADE + 3 * N_SHADE_Q, C_ALLOC = C_DONE + 1, N_COUNTS = C_ALLOC + 1, C_STRIDE = 32 };
 
 struct WfState {
-    LaneRec*  rec;
-    uint32_t* q_ext[2];
-    uint32_t* q_shade[N_SHADE_Q];
+    float4*   ray_o;      // origin, time
+    float4*   ray_d;      // direction (w unused)
+    int4*     hit;        // bits of t, id, face (signature worlds: 8 * entry + face), unused
+    int4*     uv;         // scenes with image textures: the earlier uv-writing hit (id, face, bits of t)
+    float4*   thr;        // running product of the path (accumCol of color()), bounces done (integer bits)
+    float4*   acc;        // pixel sum, samples finished (integer bits)
+    uint64_t* rng;        // PCG state (the increment is (pixel << 1) | 1)
+    uint32_t* pix;        // pixel index i = ytop * nx + x
+    uint32_t* q_ext[3];
+    uint32_t* q_shade[2][N_SHADE_Q];
     unsigned* counts;
-    uint32_t  n;          // lanes
 };
 
-__device__ __forceinline__ void queue_push(uint32_t* q, unsigned* count, bool pred, uint32_t value)
+// Which sets a round reads, appends to and clears.
+struct RoundSets {
+    int e_in, e_out, e_zero;        // extend queue: consumed, produced (by both stages), cleared
+    int s_in, s_out, s_zero;        // shade queue lengths: consumed by the shade stage, produced by the search, cleared
+    int s_in_arr, s_out_arr;        // shade queue arrays (two sets)
+};
+
+// Queue appends are staged per workgroup: a workgroup takes WF_CHUNK (or fewer) consecutive entries of its
+// input queue, collects what its lanes append in LDS -- a wave's ballot gives the count, one LDS atomic by
+// its first lane the wave's place, the popcount of lower lanes each lane's slot -- and reserves room in
+// each output queue with ONE global atomic per chunk before copying the staged entries out together.  With
+// one global atomic per wave and queue, a round over a million lanes spent 450 us on 20 000 atomics to
+// the same few lines and 40 us on everything else.
+constexpr int WF_CHUNK = 1024;              // most entries a workgroup stages between two flushes
+constexpr unsigned WF_TARGET_CHUNKS = 1024; // a queue is cut into about this many chunks (of 256 .. WF_CHUNK entries)
+template <int ROWS>
+struct Staging {
+    uint32_t buf[ROWS][WF_CHUNK];
+    unsigned n[ROWS], base[ROWS];
+    unsigned done;
+};
+__device__ __forceinline__ unsigned chunk_size(unsigned count)
+{
+    const unsigned per = (count + WF_TARGET_CHUNKS - 1) / WF_TARGET_CHUNKS;
+    return std::min<unsigned>(WF_CHUNK, std::max(256u, (per + 255u) & ~255u));
+}
+template <int ROWS>
+__device__ __forceinline__ void stage_reset(Staging<ROWS>& s)
+{
+    if (threadIdx.x < ROWS) s.n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s.done = 0;
+    __syncthreads();
+}
+template <int ROWS>
+__device__ __forceinline__ void stage_push(Staging<ROWS>& s, int row, bool pred, uint32_t value)
 {
     const unsigned long long mask = __ballot(pred);
     if (mask == 0) return;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)mask) - 1;
     unsigned base = 0;
-    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(mask));
+    if (lane == leader) base = atomicAdd(&s.n[row], (unsigned)__popcll(mask));
     base = __shfl(base, leader);
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (pred) q[base + (unsigned)__popcll(mask & lower)] = value;
+    if (pred) s.buf[row][base + (unsigned)__popcll(mask & lower)] = value;
 }
+// Row 0 goes to extend queue e_out, row r >= 1 to material queue r - 1 of the shade set (s_out, s_out_arr);
+// the workgroup's tally of lanes that left the render goes to counter `tally`.
+template <int ROWS>
+__device__ __forceinline__ void stage_flush(Staging<ROWS>& s, const WfState& w, int rows_used, int e_out, int s_out, int s_out_arr, int tally)
+{
+    __syncthreads();
+    const int t = (int)threadIdx.x;
+    if (t < rows_used && s.n[t] > 0) {
+        unsigned* c = (t == 0) ? &w.counts[C_STRIDE * (C_EXT + e_out)] : &w.counts[C_STRIDE * (C_SHADE + N_SHADE_Q * s_out + t - 1)];
+        s.base[t] = atomicAdd(c, s.n[t]);
+    }
+    if (t == 64 && s.done > 0) atomicAdd(&w.counts[C_STRIDE * tally], s.done);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        if (r < rows_used) {
+            uint32_t* q = (r == 0) ? w.q_ext[e_out] : w.q_shade[s_out_arr][r - 1];
+            const unsigned n = s.n[r], base = s.base[r];
+            for (unsigned k = threadIdx.x; k < n; k += blockDim.x) q[base + k] = s.buf[r][k];
+        }
+    }
+    __syncthreads();
+}
+template <uint32_t F> struct StageRows {     // the next extend queue, then the material queues the mask can fill
+    static constexpr int value = (F & F_ISOTROPIC) ? 2 + Q_ISOTROPIC : (F & F_DIELECTRIC) ? 2 + Q_DIELECTRIC : (F & F_METAL) ? 2 + Q_METAL : 2;
+};
 
-__device__ __forceinline__ Ray load_ray(const LaneRec& c)
-{
-    Ray r;
-    r.o = mk(c.ray[0], c.ray[1], c.ray[2]);
-    r.d = mk(c.ray[3], c.ray[4], c.ray[5]);
-    r.time = c.ray[6];
-    return r;
-}
-__device__ __forceinline__ void store_ray(LaneRec& c, const Ray& r)
-{
-    c.ray[0] = r.o.x; c.ray[1] = r.o.y; c.ray[2] = r.o.z;
-    c.ray[3] = r.d.x; c.ray[4] = r.d.y; c.ray[5] = r.d.z;
-    c.ray[6] = r.time;
-}
-__device__ __forceinline__ V3 load3(const float* a) { return mk(a[0], a[1], a[2]); }
-__device__ __forceinline__ void store3(float* a, V3 v) { a[0] = v.x; a[1] = v.y; a[2] = v.z; }
+// Signature worlds shade from the face table (shade_sig); every workgroup keeps a copy in LDS.
+template <uint32_t F, class W> struct WfFaces { static constexpr bool used = false; static constexpr int float4s = 1; };
+template <uint32_t F, int... K> struct WfFaces<F, WorldSig<K...>> {
+    static constexpr bool used = (F & ~ptk::M_CORNELL) == 0;
+    static constexpr int float4s = used ? (int)sizeof...(K) * 8 * (SIG_FACE / 4) : 1;
+};
 
 // The path of lane l ended with running product thr: accumulate it (deNan, src/ptMain.cu:46-53,161)
 // and start the pixel's next sample (src/ptMain.cu:156-160), or write the pixel when it was the last.
 // Returns true when a fresh camera ray was stored and the lane must go to the next extend stage.
-__device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& ra, LaneRec& c,
-                                         V3 thr, Pcg& rng, float* __restrict__ out)
+__device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& ra, const WfState& w, uint32_t l, uint32_t i,
+                                         V3 acc, int s, V3 thr, Pcg& rng, float* __restrict__ out)
 {
-    V3 acc = load3(c.acc);
-    int s = c.sample;
-    const uint32_t i = c.pix;
     const int x = (int)(i % (uint32_t)ra.nx), ytop = (int)(i / (uint32_t)ra.nx);
     const int y = ra.ny - 1 - ytop;
     while (true) {
@@ -111,7 +158,6 @@ __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& 
             out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, acc.x * inv_ns));
             out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, acc.y * inv_ns));
             out[3 * (size_t)i + 2] = sqrtf(fmaxf(0.0f, acc.z * inv_ns));
-            c.sample = s;
             return false;
         }
         float u = ((float)x + rng.rand()) / (float)ra.nx;
@@ -119,11 +165,10 @@ __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& 
         const Ray r = camera_ray(sv, u, v, rng);
         thr = mk(1, 1, 1);
         if (ra.max_depth > 0) {
-            store_ray(c, r);
-            store3(c.thr, thr);
-            store3(c.acc, acc);
-            c.sample = s;
-            c.depth = 0;
+            w.ray_o[l] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
+            w.ray_d[l] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+            w.thr[l] = make_float4(1, 1, 1, __int_as_float(0));
+            w.acc[l] = make_float4(acc.x, acc.y, acc.z, __int_as_float(s));
             return true;
         }
         // bounce limit 0: color() returns (1,1,1) without tracing; loop to the next sample
@@ -132,140 +177,194 @@ __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& 
 
 __global__ __launch_bounds__(256) void k_wf_init(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
 {
+    __shared__ Staging<1> stage;
+    stage_reset(stage);
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     int x = 0, ytop = 0;
     const bool live = wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop);
-    // lanes are numbered densely in launch order; dead lanes (image edge) get no slot
-    const unsigned long long mask = __ballot(live);
-    unsigned base = 0;
-    if (mask != 0) {
-        const int leader = __ffsll((long long)mask) - 1;
-        if (lane == leader) base = atomicAdd(&w.counts[C_DONE + 1], (unsigned)__popcll(mask));   // slot allocator
-        base = __shfl(base, leader);
-    }
+    // lane number = place in the launch; dead lanes (image edge) are never queued.  The workgroup's
+    // tally here is of the lanes that own a pixel and did not finish it on the spot.
+    const uint32_t l = (uint32_t)wave * 64u + (uint32_t)lane;
     bool go = false;
-    uint32_t l = 0;
     if (live) {
-        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        l = base + (unsigned)__popcll(mask & lower);
         const unsigned i = (unsigned)(ytop * ra.nx + x);
-        LaneRec& c = w.rec[l];
-        c.pix = i;
+        w.pix[l] = i;
         Pcg rng;
         rng.seed(i);
-        c.sample = -1;                                   // end_path's first increment makes it 0
-        store3(c.acc, mk(0, 0, 0));
-        // "end" a virtual empty path whose contribution is exactly zero: acc stays 0 + 0
-        go = end_path(sv, ra, c, mk(0, 0, 0), rng, out);
-        c.rng = rng.state;
-        if (!go) atomicAdd(&w.counts[C_DONE], 1u);
+        // "end" a virtual empty path whose contribution is exactly zero: the sum stays 0 + 0, and the
+        // sample count goes from -1 to 0
+        go = end_path(sv, ra, w, l, i, mk(0, 0, 0), -1, mk(0, 0, 0), rng, out);
+        w.rng[l] = rng.state;
+        if (go) atomicAdd(&stage.done, 1u);
     }
-    queue_push(w.q_ext[0], &w.counts[C_EXT0], live && go, l);
+    stage_push(stage, 0, live && go, l);
+    stage_flush(stage, w, 1, 0, 0, 0, C_ALLOC);
 }
 
-template <uint32_t F>
-__global__ __launch_bounds__(256) void k_wf_extend(SceneView sv, RenderArgs ra, WfState w, int parity, float* __restrict__ out)
+// The search: world->hit for the lanes of the extend queue.
+template <uint32_t F, class W>
+__device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs,
+                                             float* __restrict__ out, int* my_stack, const float4* faces, Staging<StageRows<F>::value>& stage,
+                                             unsigned block, unsigned n_blocks)
 {
-    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
-    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
-    const unsigned count = w.counts[C_EXT0 + parity];
-    const unsigned stride = gridDim.x * blockDim.x;
-    // whole waves iterate together so the ballots in queue_push see every lane of the wave
-    for (unsigned base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += stride) {
-        const unsigned idx = base + (threadIdx.x & 63);
+    const unsigned count = w.counts[C_STRIDE * (C_EXT + rs.e_in)];
+    const unsigned chunk = chunk_size(count);
+    const unsigned n_chunks = (count + chunk - 1) / chunk;
+    // every loop bound is the same for all lanes of the workgroup: the staging calls hold barriers
+    for (unsigned c = block; c < n_chunks; c += n_blocks) {
+      stage_reset(stage);
+      for (unsigned it = 0; it < chunk; it += blockDim.x) {
+        const unsigned idx = c * chunk + it + threadIdx.x;
         const bool active = idx < count;
         uint32_t l = 0;
         int kind = -1;
         bool again = false;
         if (active) {
-            l = w.q_ext[parity][idx];
-            LaneRec& c = w.rec[l];
-            Ray ray = load_ray(c);
+            l = w.q_ext[rs.e_in][idx];
+            const float4 o4 = w.ray_o[l], d4 = w.ray_d[l];
+            Ray ray;
+            ray.o = mk(o4.x, o4.y, o4.z); ray.d = mk(d4.x, d4.y, d4.z); ray.time = o4.w;
+            // only a medium draws a random number inside the search; other worlds fetch the lane's
+            // random state when its path ends here
             Pcg rng;
-            rng.state = c.rng;
-            rng.inc = ((uint64_t)c.pix << 1u) | 1u;
+            rng.state = 0; rng.inc = 1;
+            uint32_t i = 0;
+            if (F & F_MEDIUM) { i = w.pix[l]; rng.state = w.rng[l]; rng.inc = ((uint64_t)i << 1u) | 1u; }
             Hit h;
-            V3 thr = load3(c.thr);
-            bool ended = false;
-            if (world_hit<F>(sv, ray, 0.001f, FLT_MAX, h, rng, my_stack)) {
-                int mat;
-                if ((F & F_MEDIUM) && h.id >= PT_ID_MEDIUM_BASE) mat = sv.media[h.id - PT_ID_MEDIUM_BASE].material;
-                else mat = sv.shapes[h.id].material;
-                const int mtype = sv.materials[mat].type;
+            bool ended = false, lamp = false;
+            if (world_hit<F, W>(sv, ray, 0.001f, FLT_MAX, h, rng, my_stack)) {
+                int mtype;
+                if constexpr (WfFaces<F, W>::used) {
+                    mtype = __float_as_int(faces[(SIG_FACE / 4) * h.sig_code + 3].w);
+                } else {
+                    int mat;
+                    if ((F & F_MEDIUM) && h.id >= PT_ID_MEDIUM_BASE) mat = sv.media[h.id - PT_ID_MEDIUM_BASE].material;
+                    else mat = sv.shapes[h.id].material;
+                    mtype = sv.materials[mat].type;
+                }
                 if (mtype == PT_MAT_DIFFUSE_LIGHT) {
-                    ended = !shade<F>(sv, ray, h, thr, rng);          // emits and ends the path
+                    ended = true; lamp = true;                        // emits and ends the path
                 } else {
                     kind = (mtype == PT_MAT_METAL) ? Q_METAL : (mtype == PT_MAT_DIELECTRIC) ? Q_DIELECTRIC
                          : (mtype == PT_MAT_ISOTROPIC) ? Q_ISOTROPIC : Q_LAMBERT;
-                    c.hit_t = h.t; c.hit_id = h.id; c.hit_face = h.face;
-                    if (F & F_IMAGE) { c.uv_id = h.uv_id; c.uv_face = h.uv_face; c.uv_t = h.uv_t; }
+                    w.hit[l] = make_int4(__float_as_int(h.t), h.id, WfFaces<F, W>::used ? h.sig_code : h.face, 0);
+                    if (F & F_IMAGE) w.uv[l] = make_int4(h.uv_id, h.uv_face, __float_as_int(h.uv_t), 0);
                 }
             } else {
-                shade_miss<F>(sv, ray, thr);
                 ended = true;
             }
             if (ended) {
-                again = end_path(sv, ra, c, thr, rng, out);
-                if (!again) atomicAdd(&w.counts[C_DONE], 1u);
+                if (!(F & F_MEDIUM)) { i = w.pix[l]; rng.state = w.rng[l]; rng.inc = ((uint64_t)i << 1u) | 1u; }
+                const float4 t4 = w.thr[l], a4 = w.acc[l];
+                V3 thr = mk(t4.x, t4.y, t4.z);
+                if (lamp) {
+                    if constexpr (WfFaces<F, W>::used) (void)shade_sig<F, W>(sv, faces, ray, h, thr, rng);
+                    else (void)shade<F>(sv, ray, h, thr, rng);
+                } else {
+                    shade_miss<F>(sv, ray, thr);
+                }
+                again = end_path(sv, ra, w, l, i, mk(a4.x, a4.y, a4.z), __float_as_int(a4.w), thr, rng, out);
+                if (!again) atomicAdd(&stage.done, 1u);
+                w.rng[l] = rng.state;
+            } else if (F & F_MEDIUM) {
+                w.rng[l] = rng.state;
             }
-            c.rng = rng.state;
         }
-        queue_push(w.q_ext[parity ^ 1], &w.counts[C_EXT0 + (parity ^ 1)], active && again, l);
-        queue_push(w.q_shade[Q_LAMBERT], &w.counts[C_SHADE + Q_LAMBERT], kind == Q_LAMBERT, l);
-        if (F & F_METAL) queue_push(w.q_shade[Q_METAL], &w.counts[C_SHADE + Q_METAL], kind == Q_METAL, l);
-        if (F & F_DIELECTRIC) queue_push(w.q_shade[Q_DIELECTRIC], &w.counts[C_SHADE + Q_DIELECTRIC], kind == Q_DIELECTRIC, l);
-        if (F & F_ISOTROPIC) queue_push(w.q_shade[Q_ISOTROPIC], &w.counts[C_SHADE + Q_ISOTROPIC], kind == Q_ISOTROPIC, l);
+        stage_push(stage, 0, active && again, l);
+        stage_push(stage, 1 + Q_LAMBERT, kind == Q_LAMBERT, l);
+        if (F & F_METAL) stage_push(stage, 1 + Q_METAL, kind == Q_METAL, l);
+        if (F & F_DIELECTRIC) stage_push(stage, 1 + Q_DIELECTRIC, kind == Q_DIELECTRIC, l);
+        if (F & F_ISOTROPIC) stage_push(stage, 1 + Q_ISOTROPIC, kind == Q_ISOTROPIC, l);
+      }
+      stage_flush(stage, w, StageRows<F>::value, rs.e_out, rs.s_out, rs.s_out_arr, C_DONE);
     }
 }
 
-// blockIdx.y selects the material queue: every wave shades one material kind.
-template <uint32_t F>
-__global__ __launch_bounds__(256) void k_wf_shade(SceneView sv, RenderArgs ra, WfState w, int parity, float* __restrict__ out)
+// Shading of one material queue: every wave shades one material kind.
+template <uint32_t F, class W>
+__device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs, int q,
+                                            float* __restrict__ out, const float4* faces, Staging<StageRows<F>::value>& stage,
+                                            unsigned block, unsigned n_blocks)
 {
-    const int q = blockIdx.y;
-    const unsigned count = w.counts[C_SHADE + q];
-    const unsigned stride = gridDim.x * blockDim.x;
-    for (unsigned base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += stride) {
-        const unsigned idx = base + (threadIdx.x & 63);
+    const unsigned count = w.counts[C_STRIDE * (C_SHADE + N_SHADE_Q * rs.s_in + q)];
+    const unsigned chunk = chunk_size(count);
+    const unsigned n_chunks = (count + chunk - 1) / chunk;
+    const uint32_t* queue = w.q_shade[rs.s_in_arr][q];
+    for (unsigned c = block; c < n_chunks; c += n_blocks) {
+      stage_reset(stage);
+      for (unsigned it = 0; it < chunk; it += blockDim.x) {
+        const unsigned idx = c * chunk + it + threadIdx.x;
         const bool active = idx < count;
         uint32_t l = 0;
         bool again = false;
         if (active) {
-            l = w.q_shade[q][idx];
-            LaneRec& c = w.rec[l];
-            Ray ray = load_ray(c);
+            l = queue[idx];
+            const float4 o4 = w.ray_o[l], d4 = w.ray_d[l], t4 = w.thr[l];
+            const int4 h4 = w.hit[l];
+            const uint32_t i = w.pix[l];
+            Ray ray;
+            ray.o = mk(o4.x, o4.y, o4.z); ray.d = mk(d4.x, d4.y, d4.z); ray.time = o4.w;
             Pcg rng;
-            rng.state = c.rng;
-            rng.inc = ((uint64_t)c.pix << 1u) | 1u;
+            rng.state = w.rng[l];
+            rng.inc = ((uint64_t)i << 1u) | 1u;
             Hit h;
-            h.t = c.hit_t; h.id = c.hit_id; h.face = c.hit_face;
+            h.t = __int_as_float(h4.x); h.id = h4.y; h.face = WfFaces<F, W>::used ? (h4.z & 7) : h4.z; h.sig_code = h4.z;
             h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
-            if (F & F_IMAGE) { h.uv_id = c.uv_id; h.uv_face = c.uv_face; h.uv_t = c.uv_t; }
-            V3 thr = load3(c.thr);
-            const bool cont = shade<F>(sv, ray, h, thr, rng);
-            int depth = c.depth + 1;
+            if (F & F_IMAGE) { const int4 u4 = w.uv[l]; h.uv_id = u4.x; h.uv_face = u4.y; h.uv_t = __int_as_float(u4.z); }
+            V3 thr = mk(t4.x, t4.y, t4.z);
+            bool cont;
+            if constexpr (WfFaces<F, W>::used) cont = shade_sig<F, W>(sv, faces, ray, h, thr, rng);
+            else cont = shade<F>(sv, ray, h, thr, rng);
+            const int depth = __float_as_int(t4.w) + 1;
             if (cont && depth < ra.max_depth) {
-                store_ray(c, ray);
-                store3(c.thr, thr);
-                c.depth = depth;
+                w.ray_o[l] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
+                w.ray_d[l] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+                w.thr[l] = make_float4(thr.x, thr.y, thr.z, __int_as_float(depth));
                 again = true;
             } else {
                 // bounce limit reached (color() returns the running product) or the path ended
-                again = end_path(sv, ra, c, thr, rng, out);
-                if (!again) atomicAdd(&w.counts[C_DONE], 1u);
+                const float4 a4 = w.acc[l];
+                again = end_path(sv, ra, w, l, i, mk(a4.x, a4.y, a4.z), __float_as_int(a4.w), thr, rng, out);
+                if (!again) atomicAdd(&stage.done, 1u);
             }
-            c.rng = rng.state;
+            w.rng[l] = rng.state;
         }
-        queue_push(w.q_ext[parity ^ 1], &w.counts[C_EXT0 + (parity ^ 1)], active && again, l);
+        stage_push(stage, 0, active && again, l);
+      }
+      stage_flush(stage, w, 1, rs.e_out, 0, 0, C_DONE);
     }
 }
 
-// After a round: the consumed extend queue and all shade queues are empty again.
-__global__ void k_wf_reset(unsigned* counts, int parity)
+// One round.  STAGES = 3: both stages in one launch, the workgroups with blockIdx.y == 0 search and
+// those with blockIdx.y == 1 + q shade material queue q; 1: the search alone; 2: the shading alone
+// (blockIdx.y = q), for worlds whose two stages want different register budgets.
+template <uint32_t F, class W, int STAGES>
+__global__ __launch_bounds__(256) void k_wf_round(SceneView sv, RenderArgs ra, WfState w, RoundSets rs, float* __restrict__ out)
 {
-    if (threadIdx.x == 0) counts[C_EXT0 + parity] = 0;
-    if (threadIdx.x >= 1 && threadIdx.x <= N_SHADE_Q) counts[C_SHADE + threadIdx.x - 1] = 0;
+    __shared__ int lds_stack[((STAGES & 1) && (F & (F_LBVH | F_REFBVH))) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ float4 faces[WfFaces<F, W>::float4s];
+    __shared__ Staging<StageRows<F>::value> stage;
+    if constexpr (WfFaces<F, W>::used) {
+        for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) faces[k] = reinterpret_cast<const float4*>(sv.sig_faces)[k];
+        __syncthreads();
+    }
+    auto search = [&]() {
+        if (blockIdx.x == 0 && threadIdx.x <= N_SHADE_Q) {           // the sets no stage of this round touches
+            if (threadIdx.x == 0) w.counts[C_STRIDE * (C_EXT + rs.e_zero)] = 0;
+            else w.counts[C_STRIDE * (C_SHADE + N_SHADE_Q * rs.s_zero + threadIdx.x - 1)] = 0;
+        }
+        int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
+        extend_stage<F, W>(sv, ra, w, rs, out, my_stack, faces, stage, blockIdx.x, gridDim.x);
+    };
+    if constexpr (STAGES == 1) {
+        search();
+    } else if constexpr (STAGES == 2) {
+        shade_stage<F, W>(sv, ra, w, rs, (int)blockIdx.y, out, faces, stage, blockIdx.x, gridDim.x);
+    } else {
+        if (blockIdx.y == 0) search();
+        else shade_stage<F, W>(sv, ra, w, rs, (int)blockIdx.y - 1, out, faces, stage, blockIdx.x, gridDim.x);
+    }
 }
 
 bool hip_ok2(hipError_t e, const char* what)
@@ -277,26 +376,45 @@ bool hip_ok2(hipError_t e, const char* what)
     return false;
 }
 
-template <uint32_t F>
-void launch_round(const SceneView& sv, const RenderArgs& ra, const WfState& w, int parity, int n_shade_q, unsigned blocks,
+template <uint32_t F, class W, bool SPLIT>
+void launch_round(const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs, int n_shade_q, unsigned blocks,
                   float* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_wf_extend<F>, dim3(blocks), dim3(256), 0, st, sv, ra, w, parity, out);
-    hipLaunchKernelGGL(k_wf_shade<F>, dim3(blocks, n_shade_q), dim3(256), 0, st, sv, ra, w, parity, out);
-    hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, st, w.counts, parity);
+    if (SPLIT) {
+        hipLaunchKernelGGL((k_wf_round<F, W, 1>), dim3(blocks), dim3(256), 0, st, sv, ra, w, rs, out);
+        hipLaunchKernelGGL((k_wf_round<F, W, 2>), dim3(blocks, n_shade_q), dim3(256), 0, st, sv, ra, w, rs, out);
+    } else {
+        hipLaunchKernelGGL((k_wf_round<F, W, 3>), dim3(blocks, 1 + n_shade_q), dim3(256), 0, st, sv, ra, w, rs, out);
+    }
 }
 
-void launch_round_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, int parity, int nq,
+// The feature mask of the kernels a scene variant runs on (what launch_round_variant instantiates): it,
+// not the scene's own mask, decides which lane fields the kernels touch.
+uint32_t variant_mask(int variant)
+{
+    using namespace ptk;
+    switch (variant) {
+    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: case V_CORNELL: return M_CORNELL;
+    case V_SPHERES: return M_SPHERES;
+    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: return M_SPHERES_LBVH;
+    case V_TRIMESH: case V_TRIMESH4: return M_TRIMESH;
+    case V_ALL: case V_FINAL: return M_ALL;
+    default: return M_ALL_LBVH;
+    }
+}
+
+void launch_round_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs, int nq,
                           unsigned blocks, float* out, hipStream_t st)
 {
     using namespace ptk;
     switch (variant) {
-    case V_CORNELL: case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_round<M_CORNELL>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case V_SPHERES: launch_round<M_SPHERES>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: launch_round<M_SPHERES_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case V_TRIMESH: case V_TRIMESH4: launch_round<M_TRIMESH>(sv, ra, w, parity, nq, blocks, out, st); break;
-    case V_ALL: case V_FINAL: launch_round<M_ALL>(sv, ra, w, parity, nq, blocks, out, st); break;
-    default: launch_round<M_ALL_LBVH>(sv, ra, w, parity, nq, blocks, out, st); break;
+    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_round<M_CORNELL, CornellWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    case V_CORNELL: launch_round<M_CORNELL, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    case V_SPHERES: launch_round<M_SPHERES, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: launch_round<M_SPHERES_LBVH, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    case V_TRIMESH: case V_TRIMESH4: launch_round<M_TRIMESH, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    case V_ALL: case V_FINAL: launch_round<M_ALL, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    default: launch_round<M_ALL_LBVH, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
     }
 }
 
@@ -306,26 +424,45 @@ namespace pt {
 
 int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_t st)
 {
+    constexpr int HOST_SLOT = 64;          // words per pinned copy of the finished / allocated counters
+
     const uint32_t n_slots = (uint32_t)ra.n_wave_tiles * 64u;
     if (n_slots == 0) return PT_OK;
-    // one allocation: the lane records, then the queues and counters.  The scene keeps it between calls
+    // one allocation: the lane fields, then the queues and counters.  The scene keeps it between calls
     // (a host that renders frame after frame pays for it once); it grows when a larger shard comes along.
-    const size_t bytes = (size_t)n_slots * sizeof(LaneRec) + (size_t)n_slots * (2 + N_SHADE_Q) * 4 + 64 * 4;
+    const uint32_t kernel_mask = variant_mask(sc->variant);
+    const bool image = (kernel_mask & F_IMAGE) != 0;      // the kernels compiled with image textures keep the uv field
+    const size_t per_lane = 16 * (image ? 6 : 5) + 8 + 4 + 4 * (3 + 2 * N_SHADE_Q);
+    const size_t counts_bytes = (size_t)N_COUNTS * C_STRIDE * 4;
+    const size_t bytes = (size_t)n_slots * per_lane + counts_bytes;
     if (sc->wf_workspace_bytes < bytes) {
         if (sc->wf_workspace) { (void)hipFree(sc->wf_workspace); sc->wf_workspace = nullptr; sc->wf_workspace_bytes = 0; }
         if (!hip_ok2(hipMalloc(&sc->wf_workspace, bytes), "hipMalloc(wavefront state)")) return PT_ERR_OOM;
         sc->wf_workspace_bytes = bytes;
     }
+    if (!sc->wf_host) {
+        void* h = nullptr;
+        if (!hip_ok2(hipHostMalloc(&h, 2 * HOST_SLOT * sizeof(unsigned), hipHostMallocDefault), "hipHostMalloc(wavefront counters)")) return PT_ERR_OOM;
+        sc->wf_host = static_cast<unsigned*>(h);
+        for (hipEvent_t& e : sc->wf_ev)
+            if (!hip_ok2(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return PT_ERR_HIP;
+    }
     char* p = static_cast<char*>(sc->wf_workspace);
     WfState w{};
-    w.n = n_slots;
     auto take = [&](size_t nbytes) { char* r = p; p += nbytes; return r; };
-    w.rec = reinterpret_cast<LaneRec*>(take((size_t)n_slots * sizeof(LaneRec)));
-    w.q_ext[0] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
-    w.q_ext[1] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
-    for (int q = 0; q < N_SHADE_Q; q++) w.q_shade[q] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
-    w.counts = reinterpret_cast<unsigned*>(take(64 * 4));
-    if (!hip_ok2(hipMemsetAsync(w.counts, 0, 64 * 4, st), "hipMemsetAsync(counts)")) return PT_ERR_HIP;
+    w.ray_o = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
+    w.ray_d = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
+    w.hit = reinterpret_cast<int4*>(take((size_t)n_slots * 16));
+    w.thr = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
+    w.acc = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
+    w.uv = image ? reinterpret_cast<int4*>(take((size_t)n_slots * 16)) : nullptr;
+    w.rng = reinterpret_cast<uint64_t*>(take((size_t)n_slots * 8));
+    w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
+    for (int k = 0; k < 3; k++) w.q_ext[k] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
+    for (int a = 0; a < 2; a++)
+        for (int q = 0; q < N_SHADE_Q; q++) w.q_shade[a][q] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
+    w.counts = reinterpret_cast<unsigned*>(take(counts_bytes));
+    if (!hip_ok2(hipMemsetAsync(w.counts, 0, counts_bytes, st), "hipMemsetAsync(counts)")) return PT_ERR_HIP;
 
     hipLaunchKernelGGL(k_wf_init, dim3((ra.n_wave_tiles + 3) / 4), dim3(256), 0, st, sc->view, ra, w, d_out);
     if (!hip_ok2(hipGetLastError(), "wavefront init launch")) return PT_ERR_HIP;
@@ -333,25 +470,49 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
 
     // which shade queues can be non-empty for this scene
     int n_shade_q = 1;
-    if (sc->mask & F_METAL) n_shade_q = Q_METAL + 1;
-    if (sc->mask & F_DIELECTRIC) n_shade_q = Q_DIELECTRIC + 1;
-    if (sc->mask & F_ISOTROPIC) n_shade_q = Q_ISOTROPIC + 1;
-    const unsigned blocks = std::min<unsigned>((n_slots + 255) / 256, 4096u);
+    if (sc->mask & kernel_mask & F_METAL) n_shade_q = Q_METAL + 1;
+    if (sc->mask & kernel_mask & F_DIELECTRIC) n_shade_q = Q_DIELECTRIC + 1;
+    if (sc->mask & kernel_mask & F_ISOTROPIC) n_shade_q = Q_ISOTROPIC + 1;
 
-    unsigned host_counts[N_COUNTS + 1];
-    int parity = 0;
-    const int rounds_per_check = 32;
-    while (true) {
-        for (int r = 0; r < rounds_per_check; r++) {
-            launch_round_variant(sc->variant, sc->view, ra, w, parity, n_shade_q, blocks, d_out, st);
-            parity ^= 1;
-            launches += 3;
+    // Rounds are enqueued a chunk at a time; the finished-lane count of chunk c is copied out behind it
+    // and read once chunk c + 1 is queued, so the GPU never waits for the host's decision.  The count
+    // also bounds the lanes still alive, which sizes the next chunk's launches.
+    const int rounds_per_chunk = 32;
+    // a lane is searched in one round and shaded in the next, and a pixel is at most ns paths of
+    // max_depth bounces plus the round that ends each: more rounds than that mean a lane was lost
+    const long long round_limit = 2ll * ra.ns * ((long long)ra.max_depth + 2) + 4 * rounds_per_chunk;
+    uint32_t live = n_slots;
+    int round = 0;
+    bool finished = false;
+    for (int chunk = 0; !finished; chunk++) {
+        // enough workgroups for every chunk the kernels will cut `live` queue entries into (chunk_size)
+        const unsigned blocks = std::max(1u, std::min<unsigned>((live + 255) / 256, std::max<unsigned>(WF_TARGET_CHUNKS, (live + WF_CHUNK - 1) / WF_CHUNK)));
+        for (int k = 0; k < rounds_per_chunk; k++, round++) {
+            RoundSets rs;
+            rs.e_in = round % 3; rs.e_out = (round + 1) % 3; rs.e_zero = (round + 2) % 3;
+            rs.s_out = round % 3; rs.s_in = (round + 2) % 3; rs.s_zero = (round + 1) % 3;
+            rs.s_out_arr = round & 1; rs.s_in_arr = (round + 1) & 1;
+            launch_round_variant(sc->variant, sc->view, ra, w, rs, n_shade_q, blocks, d_out, st);
+            launches += 1;
         }
         if (!hip_ok2(hipGetLastError(), "wavefront round launch")) return PT_ERR_HIP;
-        if (!hip_ok2(hipMemcpyAsync(host_counts, w.counts, sizeof host_counts, hipMemcpyDeviceToHost, st), "hipMemcpyAsync(counts)")) return PT_ERR_HIP;
-        if (!hip_ok2(hipStreamSynchronize(st), "wavefront rounds")) return PT_ERR_HIP;
-        if (host_counts[C_DONE] >= host_counts[C_DONE + 1]) break;     // every allocated lane finished its pixel
+        unsigned* slot = sc->wf_host + HOST_SLOT * (chunk & 1);     // the two counters, C_STRIDE words apart
+        if (!hip_ok2(hipMemcpyAsync(slot, w.counts + C_STRIDE * C_DONE, (C_STRIDE + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(counts)")) return PT_ERR_HIP;
+        if (!hip_ok2(hipEventRecord(sc->wf_ev[chunk & 1], st), "hipEventRecord")) return PT_ERR_HIP;
+        if (chunk >= 1) {
+            const int prev = (chunk - 1) & 1;
+            if (!hip_ok2(hipEventSynchronize(sc->wf_ev[prev]), "wavefront rounds")) return PT_ERR_HIP;
+            const unsigned done = sc->wf_host[HOST_SLOT * prev], alloc = sc->wf_host[HOST_SLOT * prev + C_STRIDE];
+            if (done >= alloc) finished = true;                  // every allocated lane finished its pixel
+            else live = alloc - done;
+        }
+        if (!finished && round > round_limit) {
+            (void)hipStreamSynchronize(st);
+            pt::set_error("wavefront: the frame did not finish within the rounds its sample and bounce counts allow");
+            return PT_ERR_HIP;
+        }
     }
+    if (!hip_ok2(hipStreamSynchronize(st), "wavefront rounds")) return PT_ERR_HIP;
     sc->last.n_launches = launches;
     return PT_OK;
 }
