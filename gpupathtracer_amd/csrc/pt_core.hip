@@ -633,8 +633,6 @@ extern "C" void pt_scene_destroy(PtScene* sc)
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->bad_resume_host) (void)hipHostFree(sc->bad_resume_host);
     if (sc->wf_workspace) (void)hipFree(sc->wf_workspace);
-    if (sc->wf_host) (void)hipHostFree(sc->wf_host);
-    for (hipEvent_t e : sc->wf_ev) if (e) (void)hipEventDestroy(e);
     if (sc->staging) (void)hipFree(sc->staging);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);
@@ -744,7 +742,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         pt::set_error("pt_render_device_noalloc: the staged pipeline allocates its queues; use the fused pipeline"); return PT_ERR_UNSUPPORTED;
     }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT) {
-        const int rc = pt::render_wavefront(sc, ra, out, st);       // host-driven rounds; blocks
+        const int rc = pt::render_wavefront(sc, ra, out, st);       // one launch; blocks until it has finished
         if (rc != PT_OK) return rc;
         sc->last.pipeline = PT_PIPELINE_WAVEFRONT;
     } else {

@@ -81,8 +81,6 @@ struct PtScene {
     int* bad_resume_host = nullptr;     // pinned host word a progressive pass raises when its accumulator is not at first_sample
     int* bad_resume_dev = nullptr;      // the same word as the device sees it
     void* wf_workspace = nullptr;       // staged scheduler: lane state and queues, kept between calls
-    unsigned* wf_host = nullptr;        // staged scheduler: pinned host words the finished-lane counts are copied into
-    hipEvent_t wf_ev[2] = {nullptr, nullptr};   // staged scheduler: one event per chunk of rounds in flight
     void* staging = nullptr;            // device side of the host-buffer entry points (pt_render, pt_trace_closest, ...), kept between calls
     size_t staging_bytes = 0;
     size_t wf_workspace_bytes = 0;
@@ -112,7 +110,7 @@ struct PtScene {
     X FusedLaunch<ptk::M_ALL_LBVH4, ptd::AnyWorld>;
 
 namespace pt {
-// Staged (wavefront) scheduler, pt_wavefront.hip.  Blocks until the frame is complete.
+// Staged (wavefront) scheduler, pt_wavefront.hip: one launch; blocks until the frame is complete.
 int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_t st);
 }
 

@@ -4,30 +4,34 @@
 // (render_kernel / render_pixel / color, src/ptMain.cu:95-190).  Here the same per-pixel state
 // machine is cut at its divergent points and every stage runs over a compacted queue of pixel lanes:
 //
+//   generate : a pixel's next camera sample (at the start, and wherever a path ends)
 //   extend   : world->hit for every lane with a live ray; misses and light hits end the path in
-//              place (accumulate, start the pixel's next sample), other hits are binned by
-//              material kind
+//              place (accumulate, generate), other hits are binned by material kind
 //   shade    : one pass per material kind over its queue (lanes of a wave share the material),
 //              light / cosine mixture sampling, throughput update, next ray
 //
-// Queues hold lane numbers; a stage appends with one atomic per wave: the wave's ballot gives the
-// count, the popcount of lower lanes gives each lane its slot.  Each lane still owns one pixel and
-// carries that pixel's PCG state from sample to sample and bounce to bounce, so the image is the
-// same, bit for bit, as the fused scheduler's and the reference's.
+// Queues hold lane numbers; a stage appends with a wave ballot: the ballot gives the count, one LDS
+// atomic by the wave's first lane the wave's place in the queue, the popcount of lower lanes each
+// lane's slot.  Each lane still owns one pixel and carries that pixel's PCG state from sample to
+// sample and bounce to bounce, so the image is the same, bit for bit, as the fused scheduler's and
+// the reference's.
 //
-// Lane state is held field by field (structure of arrays, 16-byte elements where a stage reads a
-// group together), so a stage moves only what it reads or changes: the search reads the ray (32
-// bytes) and writes the hit (16), the shading reads ray, hit, running product and random state and
-// writes ray, product and state.  One launch is one round of both stages, skewed by a round: the
-// search of round r fills the shade queues that round r + 1 empties, and both feed the extend queue
-// of round r + 1, so the two stages of a launch work on different lanes and nothing in a launch
-// waits for anything else in it.  Counters rotate through three sets; the set nobody reads or
-// appends to in a round is cleared by that round's first workgroup, so a round is exactly one
-// launch.  The host enqueues rounds in chunks and reads the finished-lane count of a chunk while the
-// next one is already queued.
+// Lanes are dealt to workgroups in groups of 256 or 512 consecutive lanes (4 or 8 of the 8x8 pixel
+// tiles), and a group's queues live in its workgroup's LDS: the workgroup loops over rounds -- search
+// everything in the extend queue, barrier, shade every material queue, barrier -- until its extend
+// queue stays empty, so a frame is one launch and no queue counter is ever touched by two
+// workgroups.  (Frame-wide queues in global memory, one launch per round, were built first: a
+// device-scope atomic on a queue counter is served one at a time at about 22 ns on this part, so
+// with one atomic per wave and queue a round over a million lanes spent 450 of its 490 us on 20 000
+// atomics; staged per workgroup, one atomic per 1024 entries, the round took 120 us, and three
+// quarters of that was lanes of a wave lying anywhere in the frame's state arrays after a few rounds
+// of compaction.)  Lane state is held field by field in global memory (16-byte elements where a
+// stage reads a group together), so a stage moves only what it reads or changes, and a group's
+// lanes are neighbours in every array.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "pt_host.h"
@@ -39,98 +43,49 @@ namespace {
 
 // Queue kinds for the shade stage (material-sorted).
 enum : int { Q_LAMBERT = 0, Q_METAL = 1, Q_DIELECTRIC = 2, Q_ISOTROPIC = 3, N_SHADE_Q = 4 };
-// counts[]: three sets of the extend queue's length, three sets of the shade queues' lengths, then the
-// finished lanes and the allocated lanes.  Every counter has a 128-byte line to itself (C_STRIDE words
-// apart): an atomic on a counter is served where the line lives, one at a time -- about 22 ns each on
-// MI355X, whichever word of the line it names.
-enum : int { C_EXT = 0, C_SHADE = 3, C_DONE = C_SHADE + 3 * N_SHADE_Q, C_ALLOC = C_DONE + 1, N_COUNTS = C_ALLOC + 1, C_STRIDE = 32 };
+
+constexpr int WF_GROUP_MAX = 1024;         // most lanes of one group (its queues hold 16-bit lane numbers within the group)
 
 struct WfState {
     float4*   ray_o;      // origin, time
     float4*   ray_d;      // direction (w unused)
     int4*     hit;        // bits of t, id, face (signature worlds: 8 * entry + face), unused
-    int4*     uv;         // scenes with image textures: the earlier uv-writing hit (id, face, bits of t)
+    int4*     uv;         // kernels with image textures: the earlier uv-writing hit (id, face, bits of t)
     float4*   thr;        // running product of the path (accumCol of color()), bounces done (integer bits)
     float4*   acc;        // pixel sum, samples finished (integer bits)
     uint64_t* rng;        // PCG state (the increment is (pixel << 1) | 1)
     uint32_t* pix;        // pixel index i = ytop * nx + x
-    uint32_t* q_ext[3];
-    uint32_t* q_shade[2][N_SHADE_Q];
-    unsigned* counts;
+    int*      lost;       // raised by a workgroup that ran out of rounds with lanes still queued
+    int32_t   group_lanes;    // lanes per group: a multiple of 256, at most WF_GROUP_MAX
+    int32_t   round_limit;    // rounds after which a group gives up (a lane was lost: cannot happen, must not hang)
 };
 
-// Which sets a round reads, appends to and clears.
-struct RoundSets {
-    int e_in, e_out, e_zero;        // extend queue: consumed, produced (by both stages), cleared
-    int s_in, s_out, s_zero;        // shade queue lengths: consumed by the shade stage, produced by the search, cleared
-    int s_in_arr, s_out_arr;        // shade queue arrays (two sets)
+// The material queues a feature mask can fill.
+template <uint32_t F> struct ShadeQueues {
+    static constexpr int value = (F & F_ISOTROPIC) ? 1 + Q_ISOTROPIC : (F & F_DIELECTRIC) ? 1 + Q_DIELECTRIC : (F & F_METAL) ? 1 + Q_METAL : 1;
 };
 
-// Queue appends are staged per workgroup: a workgroup takes WF_CHUNK (or fewer) consecutive entries of its
-// input queue, collects what its lanes append in LDS -- a wave's ballot gives the count, one LDS atomic by
-// its first lane the wave's place, the popcount of lower lanes each lane's slot -- and reserves room in
-// each output queue with ONE global atomic per chunk before copying the staged entries out together.  With
-// one global atomic per wave and queue, a round over a million lanes spent 450 us on 20 000 atomics to
-// the same few lines and 40 us on everything else.
-constexpr int WF_CHUNK = 1024;              // most entries a workgroup stages between two flushes
-constexpr unsigned WF_TARGET_CHUNKS = 1024; // a queue is cut into about this many chunks (of 256 .. WF_CHUNK entries)
-template <int ROWS>
-struct Staging {
-    uint32_t buf[ROWS][WF_CHUNK];
-    unsigned n[ROWS], base[ROWS];
-    unsigned done;
+// A group's queues, in its workgroup's LDS.
+template <int NQ>
+struct GroupQueues {
+    uint16_t ext[2][WF_GROUP_MAX];      // the extend queue being read and the one being filled
+    uint16_t shade[NQ][WF_GROUP_MAX];
+    unsigned n_ext[2], n_shade[NQ];
 };
-__device__ __forceinline__ unsigned chunk_size(unsigned count)
-{
-    const unsigned per = (count + WF_TARGET_CHUNKS - 1) / WF_TARGET_CHUNKS;
-    return std::min<unsigned>(WF_CHUNK, std::max(256u, (per + 255u) & ~255u));
-}
-template <int ROWS>
-__device__ __forceinline__ void stage_reset(Staging<ROWS>& s)
-{
-    if (threadIdx.x < ROWS) s.n[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s.done = 0;
-    __syncthreads();
-}
-template <int ROWS>
-__device__ __forceinline__ void stage_push(Staging<ROWS>& s, int row, bool pred, uint32_t value)
+
+// Every lane of the wave calls this together.
+__device__ __forceinline__ void queue_push(uint16_t* q, unsigned* count, bool pred, uint32_t value)
 {
     const unsigned long long mask = __ballot(pred);
     if (mask == 0) return;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)mask) - 1;
     unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&s.n[row], (unsigned)__popcll(mask));
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(mask));
     base = __shfl(base, leader);
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (pred) s.buf[row][base + (unsigned)__popcll(mask & lower)] = value;
+    if (pred) q[base + (unsigned)__popcll(mask & lower)] = (uint16_t)value;
 }
-// Row 0 goes to extend queue e_out, row r >= 1 to material queue r - 1 of the shade set (s_out, s_out_arr);
-// the workgroup's tally of lanes that left the render goes to counter `tally`.
-template <int ROWS>
-__device__ __forceinline__ void stage_flush(Staging<ROWS>& s, const WfState& w, int rows_used, int e_out, int s_out, int s_out_arr, int tally)
-{
-    __syncthreads();
-    const int t = (int)threadIdx.x;
-    if (t < rows_used && s.n[t] > 0) {
-        unsigned* c = (t == 0) ? &w.counts[C_STRIDE * (C_EXT + e_out)] : &w.counts[C_STRIDE * (C_SHADE + N_SHADE_Q * s_out + t - 1)];
-        s.base[t] = atomicAdd(c, s.n[t]);
-    }
-    if (t == 64 && s.done > 0) atomicAdd(&w.counts[C_STRIDE * tally], s.done);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        if (r < rows_used) {
-            uint32_t* q = (r == 0) ? w.q_ext[e_out] : w.q_shade[s_out_arr][r - 1];
-            const unsigned n = s.n[r], base = s.base[r];
-            for (unsigned k = threadIdx.x; k < n; k += blockDim.x) q[base + k] = s.buf[r][k];
-        }
-    }
-    __syncthreads();
-}
-template <uint32_t F> struct StageRows {     // the next extend queue, then the material queues the mask can fill
-    static constexpr int value = (F & F_ISOTROPIC) ? 2 + Q_ISOTROPIC : (F & F_DIELECTRIC) ? 2 + Q_DIELECTRIC : (F & F_METAL) ? 2 + Q_METAL : 2;
-};
 
 // Signature worlds shade from the face table (shade_sig); every workgroup keeps a copy in LDS.
 template <uint32_t F, class W> struct WfFaces { static constexpr bool used = false; static constexpr int float4s = 1; };
@@ -175,53 +130,22 @@ __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& 
     }
 }
 
-__global__ __launch_bounds__(256) void k_wf_init(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
-{
-    __shared__ Staging<1> stage;
-    stage_reset(stage);
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int x = 0, ytop = 0;
-    const bool live = wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop);
-    // lane number = place in the launch; dead lanes (image edge) are never queued.  The workgroup's
-    // tally here is of the lanes that own a pixel and did not finish it on the spot.
-    const uint32_t l = (uint32_t)wave * 64u + (uint32_t)lane;
-    bool go = false;
-    if (live) {
-        const unsigned i = (unsigned)(ytop * ra.nx + x);
-        w.pix[l] = i;
-        Pcg rng;
-        rng.seed(i);
-        // "end" a virtual empty path whose contribution is exactly zero: the sum stays 0 + 0, and the
-        // sample count goes from -1 to 0
-        go = end_path(sv, ra, w, l, i, mk(0, 0, 0), -1, mk(0, 0, 0), rng, out);
-        w.rng[l] = rng.state;
-        if (go) atomicAdd(&stage.done, 1u);
-    }
-    stage_push(stage, 0, live && go, l);
-    stage_flush(stage, w, 1, 0, 0, 0, C_ALLOC);
-}
-
-// The search: world->hit for the lanes of the extend queue.
+// The search: world->hit for the lanes of the group's extend queue `cur`.
 template <uint32_t F, class W>
-__device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs,
-                                             float* __restrict__ out, int* my_stack, const float4* faces, Staging<StageRows<F>::value>& stage,
-                                             unsigned block, unsigned n_blocks)
+__device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, float* __restrict__ out,
+                                             int* my_stack, const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first)
 {
-    const unsigned count = w.counts[C_STRIDE * (C_EXT + rs.e_in)];
-    const unsigned chunk = chunk_size(count);
-    const unsigned n_chunks = (count + chunk - 1) / chunk;
-    // every loop bound is the same for all lanes of the workgroup: the staging calls hold barriers
-    for (unsigned c = block; c < n_chunks; c += n_blocks) {
-      stage_reset(stage);
-      for (unsigned it = 0; it < chunk; it += blockDim.x) {
-        const unsigned idx = c * chunk + it + threadIdx.x;
+    const unsigned count = gq.n_ext[cur];
+    // whole waves iterate together so the ballots in queue_push see every lane of the wave
+    for (unsigned it = 0; it < count; it += blockDim.x) {
+        const unsigned idx = it + threadIdx.x;
         const bool active = idx < count;
-        uint32_t l = 0;
+        uint32_t j = 0;
         int kind = -1;
         bool again = false;
         if (active) {
-            l = w.q_ext[rs.e_in][idx];
+            j = gq.ext[cur][idx];
+            const uint32_t l = first + j;
             const float4 o4 = w.ray_o[l], d4 = w.ray_d[l];
             Ray ray;
             ray.o = mk(o4.x, o4.y, o4.z); ray.d = mk(d4.x, d4.y, d4.z); ray.time = o4.w;
@@ -265,41 +189,33 @@ __device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderAr
                     shade_miss<F>(sv, ray, thr);
                 }
                 again = end_path(sv, ra, w, l, i, mk(a4.x, a4.y, a4.z), __float_as_int(a4.w), thr, rng, out);
-                if (!again) atomicAdd(&stage.done, 1u);
                 w.rng[l] = rng.state;
             } else if (F & F_MEDIUM) {
                 w.rng[l] = rng.state;
             }
         }
-        stage_push(stage, 0, active && again, l);
-        stage_push(stage, 1 + Q_LAMBERT, kind == Q_LAMBERT, l);
-        if (F & F_METAL) stage_push(stage, 1 + Q_METAL, kind == Q_METAL, l);
-        if (F & F_DIELECTRIC) stage_push(stage, 1 + Q_DIELECTRIC, kind == Q_DIELECTRIC, l);
-        if (F & F_ISOTROPIC) stage_push(stage, 1 + Q_ISOTROPIC, kind == Q_ISOTROPIC, l);
-      }
-      stage_flush(stage, w, StageRows<F>::value, rs.e_out, rs.s_out, rs.s_out_arr, C_DONE);
+        queue_push(gq.ext[cur ^ 1], &gq.n_ext[cur ^ 1], active && again, j);
+        queue_push(gq.shade[Q_LAMBERT], &gq.n_shade[Q_LAMBERT], kind == Q_LAMBERT, j);
+        if (F & F_METAL) queue_push(gq.shade[Q_METAL], &gq.n_shade[Q_METAL], kind == Q_METAL, j);
+        if (F & F_DIELECTRIC) queue_push(gq.shade[Q_DIELECTRIC], &gq.n_shade[Q_DIELECTRIC], kind == Q_DIELECTRIC, j);
+        if (F & F_ISOTROPIC) queue_push(gq.shade[Q_ISOTROPIC], &gq.n_shade[Q_ISOTROPIC], kind == Q_ISOTROPIC, j);
     }
 }
 
-// Shading of one material queue: every wave shades one material kind.
+// Shading of material queue q: every wave shades one material kind.
 template <uint32_t F, class W>
-__device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs, int q,
-                                            float* __restrict__ out, const float4* faces, Staging<StageRows<F>::value>& stage,
-                                            unsigned block, unsigned n_blocks)
+__device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, int q, float* __restrict__ out,
+                                            const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first)
 {
-    const unsigned count = w.counts[C_STRIDE * (C_SHADE + N_SHADE_Q * rs.s_in + q)];
-    const unsigned chunk = chunk_size(count);
-    const unsigned n_chunks = (count + chunk - 1) / chunk;
-    const uint32_t* queue = w.q_shade[rs.s_in_arr][q];
-    for (unsigned c = block; c < n_chunks; c += n_blocks) {
-      stage_reset(stage);
-      for (unsigned it = 0; it < chunk; it += blockDim.x) {
-        const unsigned idx = c * chunk + it + threadIdx.x;
+    const unsigned count = gq.n_shade[q];
+    for (unsigned it = 0; it < count; it += blockDim.x) {
+        const unsigned idx = it + threadIdx.x;
         const bool active = idx < count;
-        uint32_t l = 0;
+        uint32_t j = 0;
         bool again = false;
         if (active) {
-            l = queue[idx];
+            j = gq.shade[q][idx];
+            const uint32_t l = first + j;
             const float4 o4 = w.ray_o[l], d4 = w.ray_d[l], t4 = w.thr[l];
             const int4 h4 = w.hit[l];
             const uint32_t i = w.pix[l];
@@ -326,44 +242,77 @@ __device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArg
                 // bounce limit reached (color() returns the running product) or the path ended
                 const float4 a4 = w.acc[l];
                 again = end_path(sv, ra, w, l, i, mk(a4.x, a4.y, a4.z), __float_as_int(a4.w), thr, rng, out);
-                if (!again) atomicAdd(&stage.done, 1u);
             }
             w.rng[l] = rng.state;
         }
-        stage_push(stage, 0, active && again, l);
-      }
-      stage_flush(stage, w, 1, rs.e_out, 0, 0, C_DONE);
+        queue_push(gq.ext[cur ^ 1], &gq.n_ext[cur ^ 1], active && again, j);
     }
 }
 
-// One round.  STAGES = 3: both stages in one launch, the workgroups with blockIdx.y == 0 search and
-// those with blockIdx.y == 1 + q shade material queue q; 1: the search alone; 2: the shading alone
-// (blockIdx.y = q), for worlds whose two stages want different register budgets.
-template <uint32_t F, class W, int STAGES>
-__global__ __launch_bounds__(256) void k_wf_round(SceneView sv, RenderArgs ra, WfState w, RoundSets rs, float* __restrict__ out)
+// One workgroup renders one group of lanes, round by round.  Every loop bound below is read from
+// LDS after a barrier, so all lanes of the workgroup take the same trips and meet at every barrier.
+// Workgroups per CU the kernel is compiled for (a register cap).  Measured on MI355X with groups of 256 /
+// 512 / 1024 lanes (Mpaths/s): rectangle scene 1024^2 x256 at 4 workgroups 7 756 / 5 702 / 3 511, at 5
+// 8 461 / 5 273 / 3 505, at 6 7 122 / 4 082 / 3 087, at 8 4 349 / 2 859 / 2 370; random spheres in the tree
+// 1920x1080 x32 at 3 1 680 / 1 906 / -, at 4 2 036 / 2 162 / 2 052, at 5 1 241 / 1 428 / 1 550; RTNW final
+// through the tree x16 at 3 1 041 / 1 233 / -, at 4 1 097 / 1 225 / 1 004, at 5 473 / 571 / 719; a
+// 1000-triangle mesh at 4 542 / 459 / 326.
+__host__ __device__ constexpr int wf_min_blocks(uint32_t F)
 {
-    __shared__ int lds_stack[((STAGES & 1) && (F & (F_LBVH | F_REFBVH))) ? 4 * 64 * LBVH_LDS_STACK : 1];
+#ifdef PT_WF_BLOCKS             // kernel experiments
+    return PT_WF_BLOCKS;
+#endif
+    return (F & ~ptk::M_CORNELL) == 0 ? 5 : 4;
+}
+template <uint32_t F, class W>
+__global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
+{
+    constexpr int NQ = ShadeQueues<F>::value;
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[WfFaces<F, W>::float4s];
-    __shared__ Staging<StageRows<F>::value> stage;
+    __shared__ GroupQueues<NQ> gq;
     if constexpr (WfFaces<F, W>::used) {
         for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) faces[k] = reinterpret_cast<const float4*>(sv.sig_faces)[k];
-        __syncthreads();
     }
-    auto search = [&]() {
-        if (blockIdx.x == 0 && threadIdx.x <= N_SHADE_Q) {           // the sets no stage of this round touches
-            if (threadIdx.x == 0) w.counts[C_STRIDE * (C_EXT + rs.e_zero)] = 0;
-            else w.counts[C_STRIDE * (C_SHADE + N_SHADE_Q * rs.s_zero + threadIdx.x - 1)] = 0;
+    if (threadIdx.x < 2) gq.n_ext[threadIdx.x] = 0;
+    if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
+    __syncthreads();
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
+    const uint32_t first = blockIdx.x * (uint32_t)w.group_lanes;
+
+    // generate: the group's lanes are the pixels of consecutive 8x8 tiles; lanes off the image edge are never queued
+    for (uint32_t j = threadIdx.x; j < (uint32_t)w.group_lanes; j += blockDim.x) {
+        const uint32_t l = first + j;
+        const int wave = (int)(l >> 6), lane = (int)(l & 63);
+        int x = 0, ytop = 0;
+        const bool live = wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop);
+        bool go = false;
+        if (live) {
+            const unsigned i = (unsigned)(ytop * ra.nx + x);
+            w.pix[l] = i;
+            Pcg rng;
+            rng.seed(i);
+            // "end" a virtual empty path whose contribution is exactly zero: the sum stays 0 + 0, and the
+            // sample count goes from -1 to 0
+            go = end_path(sv, ra, w, l, i, mk(0, 0, 0), -1, mk(0, 0, 0), rng, out);
+            w.rng[l] = rng.state;
         }
-        int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
-        extend_stage<F, W>(sv, ra, w, rs, out, my_stack, faces, stage, blockIdx.x, gridDim.x);
-    };
-    if constexpr (STAGES == 1) {
-        search();
-    } else if constexpr (STAGES == 2) {
-        shade_stage<F, W>(sv, ra, w, rs, (int)blockIdx.y, out, faces, stage, blockIdx.x, gridDim.x);
-    } else {
-        if (blockIdx.y == 0) search();
-        else shade_stage<F, W>(sv, ra, w, rs, (int)blockIdx.y - 1, out, faces, stage, blockIdx.x, gridDim.x);
+        queue_push(gq.ext[0], &gq.n_ext[0], live && go, j);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int round = 0; ; round++) {
+        if (gq.n_ext[cur] == 0) break;                          // every pixel of the group is written
+        if (round >= w.round_limit) { if (threadIdx.x == 0) *w.lost = 1; break; }
+        extend_stage<F, W>(sv, ra, w, out, my_stack, faces, gq, cur, first);
+        __syncthreads();                                        // the material queues are complete
+        for (int q = 0; q < NQ; q++) shade_stage<F, W>(sv, ra, w, q, out, faces, gq, cur, first);
+        __syncthreads();                                        // the next extend queue is complete; everyone has read this round's counts
+        if (threadIdx.x == 0) gq.n_ext[cur] = 0;
+        if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
+        cur ^= 1;
+        __syncthreads();
     }
 }
 
@@ -376,20 +325,14 @@ bool hip_ok2(hipError_t e, const char* what)
     return false;
 }
 
-template <uint32_t F, class W, bool SPLIT>
-void launch_round(const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs, int n_shade_q, unsigned blocks,
-                  float* out, hipStream_t st)
+template <uint32_t F, class W>
+void launch_groups(const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned groups, float* out, hipStream_t st)
 {
-    if (SPLIT) {
-        hipLaunchKernelGGL((k_wf_round<F, W, 1>), dim3(blocks), dim3(256), 0, st, sv, ra, w, rs, out);
-        hipLaunchKernelGGL((k_wf_round<F, W, 2>), dim3(blocks, n_shade_q), dim3(256), 0, st, sv, ra, w, rs, out);
-    } else {
-        hipLaunchKernelGGL((k_wf_round<F, W, 3>), dim3(blocks, 1 + n_shade_q), dim3(256), 0, st, sv, ra, w, rs, out);
-    }
+    hipLaunchKernelGGL((k_wf_groups<F, W>), dim3(groups), dim3(256), 0, st, sv, ra, w, out);
 }
 
-// The feature mask of the kernels a scene variant runs on (what launch_round_variant instantiates): it,
-// not the scene's own mask, decides which lane fields the kernels touch.
+// The feature mask of the kernel a scene variant runs on (what launch_variant instantiates): it,
+// not the scene's own mask, decides which lane fields the kernel touches.
 uint32_t variant_mask(int variant)
 {
     using namespace ptk;
@@ -398,23 +341,26 @@ uint32_t variant_mask(int variant)
     case V_SPHERES: return M_SPHERES;
     case V_SPHERES_LBVH: case V_SPHERES_LBVH4: return M_SPHERES_LBVH;
     case V_TRIMESH: case V_TRIMESH4: return M_TRIMESH;
-    case V_ALL: case V_FINAL: return M_ALL;
+    case V_FINAL: return M_FINAL;
+    case V_FINAL_LBVH: case V_FINAL_LBVH4: return M_FINAL_LBVH;
+    case V_ALL: return M_ALL;
     default: return M_ALL_LBVH;
     }
 }
 
-void launch_round_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, const RoundSets& rs, int nq,
-                          unsigned blocks, float* out, hipStream_t st)
+void launch_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned groups, float* out, hipStream_t st)
 {
     using namespace ptk;
     switch (variant) {
-    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_round<M_CORNELL, CornellWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
-    case V_CORNELL: launch_round<M_CORNELL, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
-    case V_SPHERES: launch_round<M_SPHERES, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
-    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: launch_round<M_SPHERES_LBVH, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
-    case V_TRIMESH: case V_TRIMESH4: launch_round<M_TRIMESH, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
-    case V_ALL: case V_FINAL: launch_round<M_ALL, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
-    default: launch_round<M_ALL_LBVH, AnyWorld, false>(sv, ra, w, rs, nq, blocks, out, st); break;
+    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_groups<M_CORNELL, CornellWorld>(sv, ra, w, groups, out, st); break;
+    case V_CORNELL: launch_groups<M_CORNELL, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_SPHERES: launch_groups<M_SPHERES, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: launch_groups<M_SPHERES_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_TRIMESH: case V_TRIMESH4: launch_groups<M_TRIMESH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_FINAL: launch_groups<M_FINAL, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_FINAL_LBVH: case V_FINAL_LBVH4: launch_groups<M_FINAL_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_ALL: launch_groups<M_ALL, AnyWorld>(sv, ra, w, groups, out, st); break;
+    default: launch_groups<M_ALL_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
     }
 }
 
@@ -424,96 +370,58 @@ namespace pt {
 
 int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_t st)
 {
-    constexpr int HOST_SLOT = 64;          // words per pinned copy of the finished / allocated counters
-
     const uint32_t n_slots = (uint32_t)ra.n_wave_tiles * 64u;
     if (n_slots == 0) return PT_OK;
-    // one allocation: the lane fields, then the queues and counters.  The scene keeps it between calls
-    // (a host that renders frame after frame pays for it once); it grows when a larger shard comes along.
+    // Group size.  Small groups win (table at wf_min_blocks): a group is one workgroup's worth of
+    // parallelism however many lanes it holds, a frame of larger groups is fewer workgroups than the GPU
+    // has room for, and the launch ends with its slowest group.  Worlds searched through a tree of boxes
+    // and spheres gain a little from 512 (their rounds are long, the barriers between stages few).
     const uint32_t kernel_mask = variant_mask(sc->variant);
+    int group_lanes = ((kernel_mask & (F_LBVH | F_REFBVH)) && !(sc->mask & F_TRIANGLE) && n_slots >= 512u * 1024u) ? 512 : 256;
+#ifdef PT_WF_BLOCKS
+    if (const char* e = getenv("PT_WF_GROUP")) group_lanes = atoi(e);
+#endif
+    const unsigned groups = (n_slots + (uint32_t)group_lanes - 1) / (uint32_t)group_lanes;
+    const uint32_t n_lanes = groups * (uint32_t)group_lanes;
+    // one allocation: the lane fields and the flag.  The scene keeps it between calls (a host that renders
+    // frame after frame pays for it once); it grows when a larger shard comes along.
     const bool image = (kernel_mask & F_IMAGE) != 0;      // the kernels compiled with image textures keep the uv field
-    const size_t per_lane = 16 * (image ? 6 : 5) + 8 + 4 + 4 * (3 + 2 * N_SHADE_Q);
-    const size_t counts_bytes = (size_t)N_COUNTS * C_STRIDE * 4;
-    const size_t bytes = (size_t)n_slots * per_lane + counts_bytes;
+    const size_t per_lane = 16 * (image ? 6 : 5) + 8 + 4;
+    const size_t bytes = (size_t)n_lanes * per_lane + 256;
     if (sc->wf_workspace_bytes < bytes) {
         if (sc->wf_workspace) { (void)hipFree(sc->wf_workspace); sc->wf_workspace = nullptr; sc->wf_workspace_bytes = 0; }
         if (!hip_ok2(hipMalloc(&sc->wf_workspace, bytes), "hipMalloc(wavefront state)")) return PT_ERR_OOM;
         sc->wf_workspace_bytes = bytes;
     }
-    if (!sc->wf_host) {
-        void* h = nullptr;
-        if (!hip_ok2(hipHostMalloc(&h, 2 * HOST_SLOT * sizeof(unsigned), hipHostMallocDefault), "hipHostMalloc(wavefront counters)")) return PT_ERR_OOM;
-        sc->wf_host = static_cast<unsigned*>(h);
-        for (hipEvent_t& e : sc->wf_ev)
-            if (!hip_ok2(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return PT_ERR_HIP;
-    }
     char* p = static_cast<char*>(sc->wf_workspace);
     WfState w{};
     auto take = [&](size_t nbytes) { char* r = p; p += nbytes; return r; };
-    w.ray_o = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
-    w.ray_d = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
-    w.hit = reinterpret_cast<int4*>(take((size_t)n_slots * 16));
-    w.thr = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
-    w.acc = reinterpret_cast<float4*>(take((size_t)n_slots * 16));
-    w.uv = image ? reinterpret_cast<int4*>(take((size_t)n_slots * 16)) : nullptr;
-    w.rng = reinterpret_cast<uint64_t*>(take((size_t)n_slots * 8));
-    w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
-    for (int k = 0; k < 3; k++) w.q_ext[k] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
-    for (int a = 0; a < 2; a++)
-        for (int q = 0; q < N_SHADE_Q; q++) w.q_shade[a][q] = reinterpret_cast<uint32_t*>(take((size_t)n_slots * 4));
-    w.counts = reinterpret_cast<unsigned*>(take(counts_bytes));
-    if (!hip_ok2(hipMemsetAsync(w.counts, 0, counts_bytes, st), "hipMemsetAsync(counts)")) return PT_ERR_HIP;
-
-    hipLaunchKernelGGL(k_wf_init, dim3((ra.n_wave_tiles + 3) / 4), dim3(256), 0, st, sc->view, ra, w, d_out);
-    if (!hip_ok2(hipGetLastError(), "wavefront init launch")) return PT_ERR_HIP;
-    int launches = 1;
-
-    // which shade queues can be non-empty for this scene
-    int n_shade_q = 1;
-    if (sc->mask & kernel_mask & F_METAL) n_shade_q = Q_METAL + 1;
-    if (sc->mask & kernel_mask & F_DIELECTRIC) n_shade_q = Q_DIELECTRIC + 1;
-    if (sc->mask & kernel_mask & F_ISOTROPIC) n_shade_q = Q_ISOTROPIC + 1;
-
-    // Rounds are enqueued a chunk at a time; the finished-lane count of chunk c is copied out behind it
-    // and read once chunk c + 1 is queued, so the GPU never waits for the host's decision.  The count
-    // also bounds the lanes still alive, which sizes the next chunk's launches.
-    const int rounds_per_chunk = 32;
-    // a lane is searched in one round and shaded in the next, and a pixel is at most ns paths of
+    w.ray_o = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+    w.ray_d = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+    w.hit = reinterpret_cast<int4*>(take((size_t)n_lanes * 16));
+    w.thr = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+    w.acc = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+    w.uv = image ? reinterpret_cast<int4*>(take((size_t)n_lanes * 16)) : nullptr;
+    w.rng = reinterpret_cast<uint64_t*>(take((size_t)n_lanes * 8));
+    w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_lanes * 4));
+    w.lost = reinterpret_cast<int*>(take(256));
+    w.group_lanes = group_lanes;
+    // a round is one bounce of every live lane of the group, and a pixel is at most ns paths of
     // max_depth bounces plus the round that ends each: more rounds than that mean a lane was lost
-    const long long round_limit = 2ll * ra.ns * ((long long)ra.max_depth + 2) + 4 * rounds_per_chunk;
-    uint32_t live = n_slots;
-    int round = 0;
-    bool finished = false;
-    for (int chunk = 0; !finished; chunk++) {
-        // enough workgroups for every chunk the kernels will cut `live` queue entries into (chunk_size)
-        const unsigned blocks = std::max(1u, std::min<unsigned>((live + 255) / 256, std::max<unsigned>(WF_TARGET_CHUNKS, (live + WF_CHUNK - 1) / WF_CHUNK)));
-        for (int k = 0; k < rounds_per_chunk; k++, round++) {
-            RoundSets rs;
-            rs.e_in = round % 3; rs.e_out = (round + 1) % 3; rs.e_zero = (round + 2) % 3;
-            rs.s_out = round % 3; rs.s_in = (round + 2) % 3; rs.s_zero = (round + 1) % 3;
-            rs.s_out_arr = round & 1; rs.s_in_arr = (round + 1) & 1;
-            launch_round_variant(sc->variant, sc->view, ra, w, rs, n_shade_q, blocks, d_out, st);
-            launches += 1;
-        }
-        if (!hip_ok2(hipGetLastError(), "wavefront round launch")) return PT_ERR_HIP;
-        unsigned* slot = sc->wf_host + HOST_SLOT * (chunk & 1);     // the two counters, C_STRIDE words apart
-        if (!hip_ok2(hipMemcpyAsync(slot, w.counts + C_STRIDE * C_DONE, (C_STRIDE + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(counts)")) return PT_ERR_HIP;
-        if (!hip_ok2(hipEventRecord(sc->wf_ev[chunk & 1], st), "hipEventRecord")) return PT_ERR_HIP;
-        if (chunk >= 1) {
-            const int prev = (chunk - 1) & 1;
-            if (!hip_ok2(hipEventSynchronize(sc->wf_ev[prev]), "wavefront rounds")) return PT_ERR_HIP;
-            const unsigned done = sc->wf_host[HOST_SLOT * prev], alloc = sc->wf_host[HOST_SLOT * prev + C_STRIDE];
-            if (done >= alloc) finished = true;                  // every allocated lane finished its pixel
-            else live = alloc - done;
-        }
-        if (!finished && round > round_limit) {
-            (void)hipStreamSynchronize(st);
-            pt::set_error("wavefront: the frame did not finish within the rounds its sample and bounce counts allow");
-            return PT_ERR_HIP;
-        }
+    const long long limit = (long long)ra.ns * ((long long)ra.max_depth + 2) + 8;
+    w.round_limit = (int32_t)std::min<long long>(limit, 0x7fffffff);
+    if (!hip_ok2(hipMemsetAsync(w.lost, 0, sizeof(int), st), "hipMemsetAsync(flag)")) return PT_ERR_HIP;
+
+    launch_variant(sc->variant, sc->view, ra, w, groups, d_out, st);
+    if (!hip_ok2(hipGetLastError(), "wavefront launch")) return PT_ERR_HIP;
+    int lost = 0;
+    if (!hip_ok2(hipMemcpyAsync(&lost, w.lost, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(flag)")) return PT_ERR_HIP;
+    if (!hip_ok2(hipStreamSynchronize(st), "wavefront render")) return PT_ERR_HIP;
+    if (lost) {
+        pt::set_error("wavefront: a group did not finish within the rounds its sample and bounce counts allow");
+        return PT_ERR_HIP;
     }
-    if (!hip_ok2(hipStreamSynchronize(st), "wavefront rounds")) return PT_ERR_HIP;
-    sc->last.n_launches = launches;
+    sc->last.n_launches = 1;
     return PT_OK;
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time of one scene at one size: python tools/quick_time.py cornell 1024 1024 256 [lbvh] [schedule N] [shards N]
+"""Kernel time of one scene at one size: python tools/quick_time.py cornell 1024 1024 256 [lbvh] [schedule N] [shards N] [wavefront]
 Development tool."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,8 @@ accel = abi.ACCEL_LBVH if "lbvh" in rest else abi.ACCEL_LBVH_BINARY if "binary" 
 kw = {}
 if "schedule" in rest:
     kw["schedule"] = int(rest[rest.index("schedule") + 1])
+if "wavefront" in rest:
+    kw["pipeline"] = abi.PIPELINE_WAVEFRONT
 if "shards" in rest:
     kw["shard_count"] = int(rest[rest.index("shards") + 1])
 pt.set_device(0)
