@@ -44,7 +44,8 @@ namespace {
 // Queue kinds for the shade stage (material-sorted).
 enum : int { Q_LAMBERT = 0, Q_METAL = 1, Q_DIELECTRIC = 2, Q_ISOTROPIC = 3, N_SHADE_Q = 4 };
 
-constexpr int WF_GROUP_MAX = 1024;         // most lanes of one group (its queues hold 16-bit lane numbers within the group)
+constexpr int WF_GROUP_MAX = 512;          // most lanes of one group (its queues hold 16-bit lane numbers within the group)
+constexpr int WF_GROUP_LDS = 256;          // lanes of a group whose state lives in LDS (LdsLanes)
 
 struct WfState {
     float4*   ray_o;      // origin, time
@@ -72,6 +73,20 @@ struct GroupQueues {
     uint16_t shade[NQ][WF_GROUP_MAX];
     unsigned n_ext[2], n_shade[NQ];
 };
+
+// Lane state of a group in its workgroup's LDS, for kernels small enough to afford it (23 KB a group):
+// the stages then read and write a lane's fields where its queues live, and nothing of a path but the
+// finished pixel ever goes to memory.  (With the fields in global memory the rectangle scene's kernel
+// spent 63 % of its wave-cycles waiting on them and wrote 64 GB per 1024^2 x256 frame.)
+template <bool ON> struct LdsLanes {};
+template <> struct LdsLanes<true> {
+    float4   ray_o[WF_GROUP_LDS], ray_d[WF_GROUP_LDS], thr[WF_GROUP_LDS], acc[WF_GROUP_LDS];
+    int4     hit[WF_GROUP_LDS];
+    uint64_t rng[WF_GROUP_LDS];
+    uint32_t pix[WF_GROUP_LDS];
+};
+// Kernels without a tree (no traversal stack in LDS) and without image textures keep their lanes in LDS.
+template <uint32_t F> struct lanes_in_lds { static constexpr bool value = (F & (F_LBVH | F_REFBVH | F_IMAGE)) == 0; };
 
 // Every lane of the wave calls this together.
 __device__ __forceinline__ void queue_push(uint16_t* q, unsigned* count, bool pred, uint32_t value)
@@ -271,6 +286,11 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[WfFaces<F, W>::float4s];
     __shared__ GroupQueues<NQ> gq;
+    __shared__ LdsLanes<lanes_in_lds<F>::value> lanes;
+    if constexpr (lanes_in_lds<F>::value) {                   // the fields are this workgroup's own: lane numbers start at 0
+        w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit = lanes.hit;
+        w.rng = lanes.rng; w.pix = lanes.pix;
+    }
     if constexpr (WfFaces<F, W>::used) {
         for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) faces[k] = reinterpret_cast<const float4*>(sv.sig_faces)[k];
     }
@@ -278,12 +298,13 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
     if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
     __syncthreads();
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
-    const uint32_t first = blockIdx.x * (uint32_t)w.group_lanes;
+    const uint32_t group_first = blockIdx.x * (uint32_t)w.group_lanes;      // the group's first lane of the launch
+    const uint32_t first = lanes_in_lds<F>::value ? 0u : group_first;          // ... and in the state arrays
 
     // generate: the group's lanes are the pixels of consecutive 8x8 tiles; lanes off the image edge are never queued
     for (uint32_t j = threadIdx.x; j < (uint32_t)w.group_lanes; j += blockDim.x) {
         const uint32_t l = first + j;
-        const int wave = (int)(l >> 6), lane = (int)(l & 63);
+        const int wave = (int)((group_first + j) >> 6), lane = (int)(j & 63);
         int x = 0, ytop = 0;
         const bool live = wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop);
         bool go = false;
@@ -381,13 +402,15 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
 #ifdef PT_WF_BLOCKS
     if (const char* e = getenv("PT_WF_GROUP")) group_lanes = atoi(e);
 #endif
+    const bool in_lds = (kernel_mask & (F_LBVH | F_REFBVH | F_IMAGE)) == 0;      // lanes_in_lds: the kernel keeps the lane fields itself
+    if (in_lds) group_lanes = WF_GROUP_LDS;
     const unsigned groups = (n_slots + (uint32_t)group_lanes - 1) / (uint32_t)group_lanes;
     const uint32_t n_lanes = groups * (uint32_t)group_lanes;
     // one allocation: the lane fields and the flag.  The scene keeps it between calls (a host that renders
     // frame after frame pays for it once); it grows when a larger shard comes along.
     const bool image = (kernel_mask & F_IMAGE) != 0;      // the kernels compiled with image textures keep the uv field
     const size_t per_lane = 16 * (image ? 6 : 5) + 8 + 4;
-    const size_t bytes = (size_t)n_lanes * per_lane + 256;
+    const size_t bytes = (in_lds ? 0 : (size_t)n_lanes * per_lane) + 256;
     if (sc->wf_workspace_bytes < bytes) {
         if (sc->wf_workspace) { (void)hipFree(sc->wf_workspace); sc->wf_workspace = nullptr; sc->wf_workspace_bytes = 0; }
         if (!hip_ok2(hipMalloc(&sc->wf_workspace, bytes), "hipMalloc(wavefront state)")) return PT_ERR_OOM;
@@ -396,14 +419,16 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
     char* p = static_cast<char*>(sc->wf_workspace);
     WfState w{};
     auto take = [&](size_t nbytes) { char* r = p; p += nbytes; return r; };
-    w.ray_o = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
-    w.ray_d = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
-    w.hit = reinterpret_cast<int4*>(take((size_t)n_lanes * 16));
-    w.thr = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
-    w.acc = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
-    w.uv = image ? reinterpret_cast<int4*>(take((size_t)n_lanes * 16)) : nullptr;
-    w.rng = reinterpret_cast<uint64_t*>(take((size_t)n_lanes * 8));
-    w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_lanes * 4));
+    if (!in_lds) {
+        w.ray_o = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+        w.ray_d = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+        w.hit = reinterpret_cast<int4*>(take((size_t)n_lanes * 16));
+        w.thr = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+        w.acc = reinterpret_cast<float4*>(take((size_t)n_lanes * 16));
+        w.uv = image ? reinterpret_cast<int4*>(take((size_t)n_lanes * 16)) : nullptr;
+        w.rng = reinterpret_cast<uint64_t*>(take((size_t)n_lanes * 8));
+        w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_lanes * 4));
+    }
     w.lost = reinterpret_cast<int*>(take(256));
     w.group_lanes = group_lanes;
     // a round is one bounce of every live lane of the group, and a pixel is at most ns paths of
