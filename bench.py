@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--cpu-spp", type=int, default=512, help="samples per pixel of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-staged", action="store_true", help="skip the one render on the staged (wavefront) pipeline reported beside the headline")
     ap.add_argument("--frame-hash", action="store_true", help="add the SHA-1 of the final frame on rank 0 to the result line")
     ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles",
                     help="tiles: whole pixels per rank, the reference's image bit for bit (default).  samples: every rank "
@@ -156,6 +157,7 @@ def main():
         return dt
 
     dt = timed(by_samples, True)
+    fused_stats = scene.stats()              # of the headline's last launch, before anything else renders
     frame_sha1 = None
     if args.frame_hash and rank == 0:       # the headline's frame, before the second sharding below overwrites it
         import hashlib
@@ -167,12 +169,26 @@ def main():
     if world > 1 and not by_samples and args.spp % world == 0:
         dt_samples = timed(True, False)
 
+    # Beside the headline (the fused pipeline), one render of the same frame on the staged pipeline
+    # (generate / extend / shade by material queue / accumulate, pt_wavefront.hip): its rate and whether
+    # its frame equals the fused one bit for bit.  Reported, never used for `value`.
+    staged = None
+    if world == 1 and not args.no_staged:
+        from gpupathtracer_amd import abi
+        fused_frame = frame.to_host().copy()
+        scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, pipeline=abi.PIPELINE_WAVEFRONT)
+        pt.synchronize()
+        st = scene.stats()
+        staged = {"value": st.paths / st.kernel_ms / 1e3, "unit": "Mpaths/s", "kernel_ms": st.kernel_ms, "launches": st.n_launches,
+                  "frame_equals_fused_bit_for_bit": bool(np.array_equal(frame.to_host().view(np.uint32), fused_frame.view(np.uint32))),
+                  "note": "PT_PIPELINE_WAVEFRONT, one launch of k_wf_groups; not part of `value`"}
+
     paths_per_step = nx * ny * args.spp
     value = paths_per_step * args.steps / dt / 1e6
     result = None
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        shard_paths = scene.stats().paths            # paths this rank's launch traced
+        shard_paths = fused_stats.paths              # paths this rank's launch traced
         flop = FLOP_PER_PATH.get(args.scene)
         roofline = None
         if flop is not None:
@@ -191,7 +207,7 @@ def main():
                     traffic_note = "the committed PMC pass profiled another build of libptcore.so; not reported"
             roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_VALU_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                        "kernel": "k_render_refill" if scene.stats().schedule == 2 else "k_render_tiles",
+                        "kernel": "k_render_refill" if fused_stats.schedule == 2 else "k_render_tiles",
                         "kernel_ms": k_ms, "flop_per_path": flop, "paths_per_launch": shard_paths,
                         "peak_note": "fp32 VALU, one add/mul per lane per cycle, no FMA credit (parity forbids contraction); compares, "
                                      "selects, min/max, fp64 and divide scale/fix-up steps issue at half that rate (%.1f TFLOP/s)"
@@ -228,6 +244,8 @@ def main():
         result["runtime"] = {"hip": hip_libs, "rccl": rccl_libs, "torch_loaded": "torch" in sys.modules}
         if frame_sha1 is not None:
             result["frame_sha1"] = frame_sha1
+        if staged is not None:
+            result["staged_pipeline"] = staged
         if dt_samples is not None:
             result["sample_batch_sharding"] = {
                 "value": paths_per_step * args.steps / dt_samples / 1e6, "unit": "Mpaths/s", "ms_per_step": dt_samples / args.steps * 1e3,

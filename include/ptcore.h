@@ -100,7 +100,8 @@ enum PtAccel {
 enum PtPipeline {
     PT_PIPELINE_DEFAULT   = 0,
     PT_PIPELINE_FUSED     = 1, /* one lane per pixel, stages fused, path regeneration in-lane   */
-    PT_PIPELINE_WAVEFRONT = 2  /* staged: generate / extend / shade (material-sorted) / light   */
+    PT_PIPELINE_WAVEFRONT = 2  /* staged: generate / extend / shade (one queue per material kind) /  */
+                               /* accumulate over compacted lane queues, round by round, one launch  */
 };
 
 /* How the fused scheduler hands pixels to lanes.  The image is the same either way. */
@@ -275,7 +276,7 @@ int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_
  * one piece of device memory the fused pipeline needs beyond the scene and the frame -- the 32-bit
  * pixel-slot counter of the persistent-lane schedules (PT_SCHEDULE_REFILL / _WALK) -- lives in a
  * 256-byte array that is part of the library's device code, one copy per GPU, instead of in memory
- * the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its queues:
+ * the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its lane state:
  * PT_ERR_UNSUPPORTED); at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
  * counter can number its pixel slots (PT_ERR_INVALID beyond); the scene's device must be current.
  * The counter is cleared at the start of every call.  All calls on one GPU share that GPU's

@@ -10,7 +10,7 @@ T="timeout -k 10"
 stats_csv() { find "$1" -name '*kernel_stats.csv' | head -1; }
 
 echo "== counters of the headline kernel (bench.py quotes their HBM traffic while the stamp matches the library)"
-$T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_tiles -- python3 bench.py --steps 1 --warmup 0 --spp 512 --no-cpu-baseline > $O/pmc_cornell.log
+$T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_tiles -- python3 bench.py --steps 1 --warmup 0 --spp 512 --no-cpu-baseline --no-staged > $O/pmc_cornell.log
 cp $O/pmc_cornell/summary.json $O/pmc_cornell1024x512_k_render_tiles.json
 mkdir -p profiles/$R && cp $O/pmc_cornell1024x512_k_render_tiles.json profiles/$R/
 echo "== bench.py default"
@@ -34,12 +34,14 @@ $T 900 python3 tools/pmc_collect.py $O/pmc_c3 k_render_refill -- python3 bench/c
 cp $O/pmc_c3/summary.json $O/pmc_c3_final_list.json
 $T 900 python3 tools/pmc_collect.py $O/pmc_c4 k_render_walk -- python3 bench/configs.py --only c4 --quick > $O/pmc_c4.log
 cp $O/pmc_c4/summary.json $O/pmc_c4_trimesh_walk.json
-$T 900 python3 tools/pmc_collect.py $O/pmc_wf_extend k_wf_extend -- python3 tools/wavefront_render.py 64 > $O/pmc_wf_extend.log
-cp $O/pmc_wf_extend/summary.json $O/pmc_wavefront_k_wf_extend.json
-$T 900 python3 tools/pmc_collect.py $O/pmc_wf_shade k_wf_shade -- python3 tools/wavefront_render.py 64 > $O/pmc_wf_shade.log
-cp $O/pmc_wf_shade/summary.json $O/pmc_wavefront_k_wf_shade.json
-$T 300 rocprofv3 --kernel-trace --stats -d $O/prof_wf --output-format csv -- python3 tools/wavefront_render.py 64 > $O/wavefront_cornell1024x64.txt
-cp "$(stats_csv $O/prof_wf)" $O/wavefront_cornell1024x64_kernel_stats.csv
+echo "== staged pipeline"
+$T 900 python3 tools/pmc_collect.py $O/pmc_wf k_wf_groups -- python3 tools/wavefront_render.py 512 > $O/pmc_wf.log
+cp $O/pmc_wf/summary.json $O/pmc_staged_cornell1024x512_k_wf_groups.json
+$T 900 python3 tools/pmc_collect.py $O/pmc_wf_c1 k_wf_groups -- python3 bench/configs.py --only c1 --quick --pipeline wavefront > $O/pmc_wf_c1.log
+cp $O/pmc_wf_c1/summary.json $O/pmc_staged_c1_rtiow_lbvh_k_wf_groups.json
+$T 600 python3 bench/configs.py --pipeline wavefront > $O/configs_1gpu_staged.jsonl
+$T 300 rocprofv3 --kernel-trace --stats -d $O/prof_wf --output-format csv -- python3 tools/wavefront_render.py 4096 > $O/staged_cornell1024x4096.txt
+cp "$(stats_csv $O/prof_wf)" $O/staged_cornell1024x4096_kernel_stats.csv
 rm -rf $O/prof_bench $O/prof_configs $O/prof_wf $O/pmc_*/
 echo "== done"
 ls $O
