@@ -340,6 +340,21 @@ def test_wavefront_scheduler_edge_cases(oracle):
     assert_bit_exact(sc2.render(64, 36, 4, pipeline=abi.PIPELINE_WAVEFRONT), sc2.render(64, 36, 4), "wavefront final+image")
 
 
+def test_wavefront_scheduler_large_frames_equal_the_fused_frame():
+    """Frames large enough for the staged scheduler's 512-lane groups (tree scenes of boxes and spheres from
+    512 x 1024 lanes on) and for more groups than the GPU holds at once, against the fused kernel's frame --
+    which the other tests hold equal to the oracle's.  Ragged edges: neither size is a multiple of 8."""
+    tex = np.random.default_rng(5).integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    for name, kw, nx, ny, ns in (("final", dict(earth_rgb=tex, accel=abi.ACCEL_LBVH), 1021, 579, 2),
+                                 ("random", dict(accel=abi.ACCEL_LBVH), 1021, 579, 2),
+                                 ("cornell", {}, 1021, 1003, 3),
+                                 ("final", dict(earth_rgb=tex), 509, 301, 2)):
+        sc = pt.Scene(pt.builtin_scene(name, nx / ny, **kw))
+        a = sc.render(nx, ny, ns, pipeline=abi.PIPELINE_WAVEFRONT)
+        assert sc.stats().pipeline == abi.PIPELINE_WAVEFRONT
+        assert_bit_exact(a, sc.render(nx, ny, ns), "%s %dx%d staged against fused" % (name, nx, ny))
+
+
 def test_cli_writes_every_image_format(tmp_path, oracle):
     """The C++ host (reference main()'s flags) renders through the C ABI and writes each format;
     8-bit pixels must be Clamp(int(255.99*c),0,255) of the oracle's frame."""
