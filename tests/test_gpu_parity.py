@@ -1174,6 +1174,7 @@ def test_random_worlds_match_the_oracle(oracle, seed):
         if ref is None:
             ref = oracle.render(g, 48, 24, 4)
         assert_bit_exact(sc.render(48, 24, 4), ref, "random world %d accel %d" % (seed, accel))
+        assert_bit_exact(sc.render(48, 24, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "random world %d accel %d staged" % (seed, accel))
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16"))))
