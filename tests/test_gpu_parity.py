@@ -340,6 +340,19 @@ def test_wavefront_scheduler_edge_cases(oracle):
     assert_bit_exact(sc2.render(64, 36, 4, pipeline=abi.PIPELINE_WAVEFRONT), sc2.render(64, 36, 4), "wavefront final+image")
 
 
+def test_configuration_c0_at_its_own_size(oracle):
+    """BASELINE configs[0] as stated: the RTIOW random-spheres scene, 200 x 100 at 16 spp -- the case the
+    reference's host-compiled path can run.  Flat list and library tree, fused and staged, against the oracle."""
+    ref = None
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+        d = pt.builtin_scene("random", 2.0, accel=accel)
+        if ref is None:
+            ref = oracle.render(d, 200, 100, 16)
+        sc = pt.Scene(d)
+        assert_bit_exact(sc.render(200, 100, 16), ref, "C0 accel %d fused" % accel)
+        assert_bit_exact(sc.render(200, 100, 16, pipeline=abi.PIPELINE_WAVEFRONT), ref, "C0 accel %d staged" % accel)
+
+
 def test_wavefront_scheduler_large_frames_equal_the_fused_frame():
     """Frames large enough for the staged scheduler's 512-lane groups (tree scenes of boxes and spheres from
     512 x 1024 lanes on) and for more groups than the GPU holds at once, against the fused kernel's frame --
