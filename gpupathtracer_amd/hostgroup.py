@@ -38,15 +38,26 @@ def mapped_runtimes():
     return sorted(hip), sorted(rccl)
 
 
+def _start_ticks(pid):
+    """Field 22 of /proc/<pid>/stat (the process's start time), or "0" where that cannot be read."""
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
 class FileGroup:
     """Rendezvous of `world` ranks through a directory on the local file system."""
 
     def __init__(self, rank, world, directory=None, timeout=300.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         if directory is None:
-            # the ranks of one launch share the launcher as parent and the port it was given
+            # the ranks of one launch share the launcher as parent and the port it was given; the parent's start
+            # time (clock ticks since boot) keeps a directory a crashed launch left behind from being taken for
+            # this one's when process ids come round again
             directory = os.path.join(os.environ.get("PT_RENDEZVOUS_ROOT", "/tmp"),
-                                     "ptgroup_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+                                     "ptgroup_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), _start_ticks(os.getppid())))
         self.dir = directory
         os.makedirs(self.dir, exist_ok=True)
         self._seq = 0
