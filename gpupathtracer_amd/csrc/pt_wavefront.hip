@@ -404,6 +404,9 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
 #endif
     const bool in_lds = (kernel_mask & (F_LBVH | F_REFBVH | F_IMAGE)) == 0;      // lanes_in_lds: the kernel keeps the lane fields itself
     if (in_lds) group_lanes = WF_GROUP_LDS;
+    if (group_lanes < 256 || group_lanes > WF_GROUP_MAX || group_lanes % 256 != 0) {      // the queues are sized for WF_GROUP_MAX lanes
+        pt::set_error("wavefront: group size must be a multiple of 256 up to WF_GROUP_MAX"); return PT_ERR_INVALID;
+    }
     const unsigned groups = (n_slots + (uint32_t)group_lanes - 1) / (uint32_t)group_lanes;
     const uint32_t n_lanes = groups * (uint32_t)group_lanes;
     // one allocation: the lane fields and the flag.  The scene keeps it between calls (a host that renders
