@@ -485,12 +485,14 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     if (want_tree && desc->n_world >= 2 && tree_sized) {
         void* d_nodes = nullptr;
         void* d_wide = nullptr;
-        // Which form the walk reads when the caller leaves it open: the binary one.  Measured on MI355X with both
-        // forms under the same register cap and schedule (binary / 4-wide, kernel ms): random spheres
-        // 1920x1080x64 47.7 / 62.0, 2 M triangles 3840x2160x16 59.7 / 63.7, RTNW final 1920x1080x64 62.2 / 63.2 --
-        // four box tests per fetch cost the vector unit more than the saved fetches give back.  The 4-wide
-        // form is built and walked on request (PT_ACCEL_LBVH_WIDE).
-        void** want_wide = desc->accel == PT_ACCEL_LBVH_WIDE ? &d_wide : nullptr;
+        // Which form the walk reads when the caller leaves it open: the 4-wide one (64-byte nodes, child boxes on a
+        // byte grid, LbvhNode4).  Measured on MI355X, binary / 4-wide under the same schedule (kernel ms): random
+        // spheres 1920x1080x64 38.0 / 35.2, 2 M triangles 3840x2160x64 185.5 / 158.1, a 20 000-triangle mesh
+        // 1920x1080x64 48.2 / 41.6, RTNW final 1920x1080x64 62.0 / 60.1.  (With 128-byte nodes holding the four boxes
+        // as floats the same comparison read 47.7 / 62.0, 59.7 / 63.7 per 16 spp, 62.2 / 63.2: four full box tests
+        // per fetch cost the vector unit more than the saved fetches gave back.)  Both forms are built; the binary
+        // one serves the walks that are not the search proper (rays lying in a plane of the tree, the node export).
+        void** want_wide = (desc->accel == PT_ACCEL_LBVH_WIDE || desc->accel == PT_ACCEL_LBVH) ? &d_wide : nullptr;
         int n_nodes = 0, root = 0, rc = PT_OK, depth = 0;
         bool built = false;
         // Tree shape by surface area for worlds of plain shapes (spheres 1920x1080x64 41.9 -> 37.9 ms, a 20 000-
@@ -723,7 +725,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // 133 / - / 55.0 with 48 waiting lanes (40: 55.9, 56: 65.9; spheres 24: 49.0, 32: 45.5, 40: 44.5, 56: 44.6).
     const bool whole_world_in_tree = (sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1;
     if (p->schedule == PT_SCHEDULE_WALK ||
-        (p->schedule == PT_SCHEDULE_AUTO && whole_world_in_tree && ((sc->mask & ptd::F_TRIANGLE) || (sc->variant == V_SPHERES_LBVH && sc->view.n_world >= 64)))) ra.refill = 2;   // a 7-sphere room: TILES 47.9, WALK 50.8
+        (p->schedule == PT_SCHEDULE_AUTO && whole_world_in_tree && ((sc->mask & ptd::F_TRIANGLE) || ((sc->variant == V_SPHERES_LBVH || sc->variant == V_SPHERES_LBVH4) && sc->view.n_world >= 64)))) ra.refill = 2;   // a 7-sphere room: TILES 47.9, WALK 50.8
     ra.walk_wait = 48;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);

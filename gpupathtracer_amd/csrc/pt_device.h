@@ -24,6 +24,7 @@
 
 namespace ptd {
 
+#define PT_FN_EARLY __host__ __device__ __forceinline__
 // ---- feature mask ---------------------------------------------------------------------
 enum : uint32_t {
     F_SPHERE     = 1u << 0,
@@ -58,15 +59,26 @@ struct LbvhNode {
     int32_t pad0, pad1;
 };
 
-// The same tree with every second level folded away: up to four children per node, boxes stored
-// by axis so that one child's six bounds sit in the same lane of six 16-byte loads.
+// The same tree with every second level folded away: up to four children per node in 64 bytes.  The
+// children's boxes are held on a grid of 256 steps per axis laid over the box that holds them all: its
+// corner, a power-of-two step per axis, and one byte per plane (low planes rounded down, high planes up, so
+// plane q of an axis -- corner + q * step, in exact arithmetic -- never lies inside the fitted box: the walk
+// may visit a child it need not have, never the reverse).  One 64-byte fetch decides four descents: half the
+// bytes and half the dependent fetches of two binary nodes.  Dword layout: 0-2 corner, 3 the three biased
+// step exponents (byte a = exponent of axis a), 4-6 low planes of x, y, z (byte c = child c), 7-9 high
+// planes, 10-13 links, 14-15 unused.
 constexpr int32_t LBVH4_EMPTY = 0x7fffffff;
 struct LbvhNode4 {
-    float bmin[3][4];      // [axis][child]
-    float bmax[3][4];
+    float   corner[3];
+    uint8_t step_exp[4];   // [axis]: the step is 2^(step_exp - 127); [3] unused
+    uint8_t lo[3][4];      // [axis][child]
+    uint8_t hi[3][4];
     int32_t link[4];       // >= 0 node, < 0 ~shape, LBVH4_EMPTY: no child
-    int32_t pad[4];
+    int32_t pad[2];
 };
+static_assert(sizeof(LbvhNode4) == 64, "one 64-byte fetch per node");
+// plane q of the grid along one axis, decoded (the walk of the rays that barely move along some axis)
+PT_FN_EARLY float lbvh4_plane(float corner, float step, unsigned q) { return corner + (float)q * step; }
 
 struct SceneView {
     const PtShape*    shapes;
@@ -780,6 +792,7 @@ __device__ __forceinline__ bool slab(const float* bmin, const float* bmax, V3 o,
 // stop stepping when too few lanes are still walking and come back later.
 struct LbvhWalk {
     V3 inv;
+    bool flat;           // a direction component is zero, denormal or out of [2^-30, 2^30]: the wide walk decodes its planes for this ray
     int cur, sp;
     float best;
     int best_id, best_face;
@@ -821,6 +834,10 @@ __device__ __forceinline__ bool ray_may_enter_tree(const SceneView& sv, const Ra
 __device__ __forceinline__ void lbvh_begin(const SceneView& sv, const Ray& r, float tmax, LbvhWalk& w)
 {
     w.inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    {
+        const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+        w.flat = !(fminf(fminf(ax, ay), az) >= 0x1p-30f && fmaxf(fmaxf(ax, ay), az) <= 0x1p30f);     // true for NaN as well
+    }
     w.cur = sv.lbvh_root;
     w.sp = 0;
     w.any = false;
@@ -877,17 +894,60 @@ __device__ __forceinline__ bool lbvh_node_step(const SceneView& sv, const Ray& r
     const float lim = sv.lbvh_cull != 0 ? w.best : tmax;
     const float from = sv.lbvh_cull != 0 ? tmin : 0.0f;
     if constexpr ((F & F_LBVH4) != 0) {
-        // one 128-byte node: four child boxes and four links.  The nearest child that the ray meets is
-        // walked next, the others wait on the stack (in no particular order: the winner of a search
-        // does not depend on the visiting order, see list_order_better; only pruning does, a little).
-        const float4* q = reinterpret_cast<const float4*>(&sv.lbvh4[w.cur]);
-        const float4 x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
-        const int4 lk = *reinterpret_cast<const int4*>(&q[6]);
+        // One 64-byte node: four child boxes on the node's byte grid and four links.  The nearest child that
+        // the ray meets is walked next, the others wait on the stack (in no particular order: the winner of a
+        // search does not depend on the visiting order, see list_order_better; only pruning does, a little).
+        // The planes are not decoded: along an axis the ray meets plane q at q * a + b with a = step * inv and
+        // b = (corner - o) * inv, one multiply-add per plane, and which of a child's two planes comes first is
+        // the sign of inv.  Rounding leaves that off by at most 2^-22 (|b| + 255 |a|); the near planes are
+        // therefore taken 2^-21 (|b| + 256 |a|) early and the far planes as much late, per axis.  A zero
+        // direction component would make a and b infinite or NaN and the axis useless (NaN, which the min/max
+        // chains ignore), so such rays take the decoded form below.
+        const int4* q = reinterpret_cast<const int4*>(&sv.lbvh4[w.cur]);
+        const int4 qa = q[0], qb = q[1], qc = q[2], qd = q[3];
+        const int4 lk = make_int4(qc.z, qc.w, qd.x, qd.y);
         float t0, t1, t2, t3;
-        const bool h0 = slab6(x0.x, y0.x, z0.x, x1.x, y1.x, z1.x, r.o, w.inv, from, lim, t0);       // link 0 is never empty
-        const bool h1 = slab6(x0.y, y0.y, z0.y, x1.y, y1.y, z1.y, r.o, w.inv, from, lim, t1);       // nor is link 1
-        const bool h2 = lk.z != LBVH4_EMPTY && slab6(x0.z, y0.z, z0.z, x1.z, y1.z, z1.z, r.o, w.inv, from, lim, t2);
-        const bool h3 = lk.w != LBVH4_EMPTY && slab6(x0.w, y0.w, z0.w, x1.w, y1.w, z1.w, r.o, w.inv, from, lim, t3);
+        bool h0, h1, h2, h3;
+#define PT_BYTE(w, c) (((unsigned)(w) >> (8 * (c))) & 0xffu)
+        if (!w.flat) {
+            const float ax = __int_as_float((qa.w & 0xff) << 23) * w.inv.x, bx = (__int_as_float(qa.x) - r.o.x) * w.inv.x;
+            const float ay = __int_as_float(((qa.w >> 8) & 0xff) << 23) * w.inv.y, by = (__int_as_float(qa.y) - r.o.y) * w.inv.y;
+            const float az = __int_as_float(((qa.w >> 16) & 0xff) << 23) * w.inv.z, bz = (__int_as_float(qa.z) - r.o.z) * w.inv.z;
+            const float ex = fmaf(0x1p-13f, fabsf(ax), 0x1p-21f * fabsf(bx));
+            const float ey = fmaf(0x1p-13f, fabsf(ay), 0x1p-21f * fabsf(by));
+            const float ez = fmaf(0x1p-13f, fabsf(az), 0x1p-21f * fabsf(bz));
+            const float bnx = bx - ex, bfx = bx + ex, bny = by - ey, bfy = by + ey, bnz = bz - ez, bfz = bz + ez;
+            const bool mx = w.inv.x < 0.0f, my = w.inv.y < 0.0f, mz = w.inv.z < 0.0f;       // the ray runs down the axis: high planes first
+            const unsigned nx = (unsigned)(mx ? qb.w : qb.x), fx = (unsigned)(mx ? qb.x : qb.w);
+            const unsigned ny = (unsigned)(my ? qc.x : qb.y), fy = (unsigned)(my ? qb.y : qc.x);
+            const unsigned nz = (unsigned)(mz ? qc.y : qb.z), fz = (unsigned)(mz ? qb.z : qc.y);
+#define PT_CHILD(c, tn_out, hit_out) \
+            { const float tn_ = fmaxf(fmaxf(fmaf((float)PT_BYTE(nx, c), ax, bnx), fmaf((float)PT_BYTE(ny, c), ay, bny)), fmaxf(fmaf((float)PT_BYTE(nz, c), az, bnz), from)); \
+              const float tf_ = fminf(fminf(fmaf((float)PT_BYTE(fx, c), ax, bfx), fmaf((float)PT_BYTE(fy, c), ay, bfy)), fminf(fmaf((float)PT_BYTE(fz, c), az, bfz), lim)); \
+              tn_out = tn_; hit_out = tn_ <= tf_; }
+            PT_CHILD(0, t0, h0)                                               // link 0 is never empty
+            PT_CHILD(1, t1, h1)                                               // nor is link 1
+            PT_CHILD(2, t2, h2)
+            PT_CHILD(3, t3, h3)
+#undef PT_CHILD
+        } else {
+            // a direction component that is zero, denormal or beyond 2^30 either way: the planes themselves,
+            // and the test the binary nodes get -- (plane - o) * inv is a signed infinity on an axis the ray
+            // does not move along, which is what decides whether the ray runs inside the child's slab
+            const float cx = __int_as_float(qa.x), cy = __int_as_float(qa.y), cz = __int_as_float(qa.z);
+            const float sx = __int_as_float((qa.w & 0xff) << 23), sy = __int_as_float(((qa.w >> 8) & 0xff) << 23),
+                        sz = __int_as_float(((qa.w >> 16) & 0xff) << 23);
+#define PT_CHILD_BOX(c) lbvh4_plane(cx, sx, PT_BYTE(qb.x, c)), lbvh4_plane(cy, sy, PT_BYTE(qb.y, c)), lbvh4_plane(cz, sz, PT_BYTE(qb.z, c)), \
+                        lbvh4_plane(cx, sx, PT_BYTE(qb.w, c)), lbvh4_plane(cy, sy, PT_BYTE(qc.x, c)), lbvh4_plane(cz, sz, PT_BYTE(qc.y, c))
+            h0 = slab6(PT_CHILD_BOX(0), r.o, w.inv, from, lim, t0);
+            h1 = slab6(PT_CHILD_BOX(1), r.o, w.inv, from, lim, t1);
+            h2 = slab6(PT_CHILD_BOX(2), r.o, w.inv, from, lim, t2);
+            h3 = slab6(PT_CHILD_BOX(3), r.o, w.inv, from, lim, t3);
+#undef PT_CHILD_BOX
+        }
+#undef PT_BYTE
+        h2 = h2 && lk.z != LBVH4_EMPTY;
+        h3 = h3 && lk.w != LBVH4_EMPTY;
         int next = LBVH4_EMPTY;
         float tn = 0.0f;
         if (h0) { next = lk.x; tn = t0; }

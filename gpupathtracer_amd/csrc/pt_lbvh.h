@@ -11,7 +11,7 @@ namespace pt {
 // strictly increasing shape indices).  d_shapes / d_xforms are the already-uploaded device
 // copies.  On success *d_nodes is a hipMalloc'ed array of *n_nodes 64-byte nodes and *root is
 // the root link (>= 0 node index, < 0 ~shape).  Returns a PtError.
-// d_wide (may be null): receives the same tree folded to four children per node (128-byte LbvhNode4,
+// d_wide (may be null): receives the same tree folded to four children per node (64-byte LbvhNode4,
 // indexed like the binary nodes; the slots of folded-away nodes stay unused).  depth (may be null):
 // levels of internal nodes of the binary tree.  area_sweep: worlds of up to 32 768 leaves take the
 // shape of their tree from a surface-area sweep on the host instead of the Morton order.

@@ -232,8 +232,8 @@ __global__ void k_emit(const int* left, const int* right, const uint64_t* keys, 
 // ---- 4-wide collapse ------------------------------------------------------------------------------------
 // Every second level of the binary tree is folded into the level above it: a node at even depth
 // keeps its slot and takes its grandchildren (or, where a child is a leaf, that leaf) as its up to
-// four children; nodes at odd depth disappear.  One 128-byte fetch then decides four descents,
-// which halves the chain of dependent node fetches of a walk.  Depth = number of parent links to
+// four children; nodes at odd depth disappear.  One 64-byte fetch then decides four descents,
+// which halves the chain of dependent node fetches of a walk, and the node is 64 bytes (LbvhNode4: boxes on a byte grid).  Depth = number of parent links to
 // the root, found by following them (trees here are a few dozen levels deep).
 __global__ void k_depth(const int* parent, int n_internal, int* depth, int* max_depth)
 {
@@ -245,16 +245,47 @@ __global__ void k_depth(const int* parent, int n_internal, int* depth, int* max_
     atomicMax(max_depth, d);
 }
 
+// The byte grid of one axis of a wide node: corner = the children's common low bound, step = the smallest
+// power of two that reaches their common high bound in 255 steps, and per child the last plane at or below
+// its low bound and the first at or above its high one -- all checked in double precision, where corner +
+// q * step is exact for every box a scene can hold (or off by 2^-53 of itself, far inside the walk's margins).
+__device__ void wide_axis(const Box* kid, int n, int a, float& corner, uint8_t& step_exp, uint8_t* lo, uint8_t* hi)
+{
+    float mn = kid[0].mn[a], mx = kid[0].mx[a];
+    for (int c = 1; c < n; c++) { mn = fminf(mn, kid[c].mn[a]); mx = fmaxf(mx, kid[c].mx[a]); }
+    corner = mn;
+    int e = 1;                                               // biased exponent: 2^-126, the smallest normal step
+    {
+        int ex = 0;
+        const float m = frexpf((mx - mn) / 255.0f, &ex);     // (mx - mn) / 255 = m * 2^ex, 0.5 <= m < 1
+        if (m > 0.0f) e = ex + 127;                           // 2^ex >= (mx - mn) / 255
+        if (e < 1) e = 1;
+        if (e > 254) e = 254;
+    }
+    while (e < 254 && !((double)mn + 255.0 * (double)__int_as_float(e << 23) >= (double)mx)) e++;
+    const double step = (double)__int_as_float(e << 23), base = (double)mn;
+    step_exp = (uint8_t)e;
+    for (int c = 0; c < 4; c++) { lo[c] = 255; hi[c] = 0; }  // no child: an empty box
+    for (int c = 0; c < n; c++) {
+        int ql = (int)floor(((double)kid[c].mn[a] - base) / step);
+        ql = ql < 0 ? 0 : ql > 255 ? 255 : ql;
+        while (ql > 0 && base + ql * step > (double)kid[c].mn[a]) ql--;                       // plane 0 is the corner itself
+        int qh = (int)ceil(((double)kid[c].mx[a] - base) / step);
+        qh = qh < 0 ? 0 : qh > 255 ? 255 : qh;
+        while (qh < 255 && base + qh * step < (double)kid[c].mx[a]) qh++;                     // plane 255 reaches the common high bound
+        lo[c] = (uint8_t)ql; hi[c] = (uint8_t)qh;
+    }
+}
+
 __global__ void k_emit_wide(const int* left, const int* right, const int* depth, const uint64_t* keys, const Box* leaf_boxes,
                             const Box* node_boxes, const PtObject* world, int n_internal, ptd::LbvhNode4* nodes)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_internal) return;
     ptd::LbvhNode4 nd;
-    for (int c = 0; c < 4; c++) {
-        for (int a = 0; a < 3; a++) { nd.bmin[a][c] = FLT_MAX; nd.bmax[a][c] = -FLT_MAX; }
-        nd.link[c] = ptd::LBVH4_EMPTY; nd.pad[c] = 0;
-    }
+    for (int a = 0; a < 3; a++) { nd.corner[a] = 0.0f; nd.step_exp[a] = 127; for (int c = 0; c < 4; c++) { nd.lo[a][c] = 255; nd.hi[a][c] = 0; } }
+    nd.step_exp[3] = 0; nd.pad[0] = 0; nd.pad[1] = 0;
+    for (int c = 0; c < 4; c++) nd.link[c] = ptd::LBVH4_EMPTY;
     if (depth[i] & 1) { nodes[i] = nd; return; }              // folded into its parent: the slot stays unused
     int kids[4], n = 0;
     const int pair[2] = { left[i], right[i] };
@@ -263,12 +294,13 @@ __global__ void k_emit_wide(const int* left, const int* right, const int* depth,
         if (c >= 0) { kids[n++] = left[c]; kids[n++] = right[c]; }
         else kids[n++] = c;
     }
+    Box kid[4];
     for (int c = 0; c < n; c++) {
         const int k = kids[c];
-        const Box b = (k >= 0) ? node_boxes[k] : leaf_boxes[(unsigned)keys[~k]];
-        for (int a = 0; a < 3; a++) { nd.bmin[a][c] = b.mn[a]; nd.bmax[a][c] = b.mx[a]; }
+        kid[c] = (k >= 0) ? node_boxes[k] : leaf_boxes[(unsigned)keys[~k]];
         nd.link[c] = (k >= 0) ? k : ~world[(unsigned)keys[~k]].index;
     }
+    for (int a = 0; a < 3; a++) wide_axis(kid, n, a, nd.corner[a], nd.step_exp[a], nd.lo[a], nd.hi[a]);
     nodes[i] = nd;
 }
 

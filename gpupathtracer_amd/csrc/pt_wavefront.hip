@@ -360,11 +360,15 @@ uint32_t variant_mask(int variant)
     switch (variant) {
     case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: case V_CORNELL: return M_CORNELL;
     case V_SPHERES: return M_SPHERES;
-    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: return M_SPHERES_LBVH;
-    case V_TRIMESH: case V_TRIMESH4: return M_TRIMESH;
+    case V_SPHERES_LBVH: return M_SPHERES_LBVH;
+    case V_SPHERES_LBVH4: return M_SPHERES_LBVH4;
+    case V_TRIMESH: return M_TRIMESH;
+    case V_TRIMESH4: return M_TRIMESH4;
     case V_FINAL: return M_FINAL;
-    case V_FINAL_LBVH: case V_FINAL_LBVH4: return M_FINAL_LBVH;
+    case V_FINAL_LBVH: return M_FINAL_LBVH;
+    case V_FINAL_LBVH4: return M_FINAL_LBVH4;
     case V_ALL: return M_ALL;
+    case V_ALL_LBVH4: return M_ALL_LBVH4;
     default: return M_ALL_LBVH;
     }
 }
@@ -376,11 +380,15 @@ void launch_variant(int variant, const SceneView& sv, const RenderArgs& ra, cons
     case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_groups<M_CORNELL, CornellWorld>(sv, ra, w, groups, out, st); break;
     case V_CORNELL: launch_groups<M_CORNELL, AnyWorld>(sv, ra, w, groups, out, st); break;
     case V_SPHERES: launch_groups<M_SPHERES, AnyWorld>(sv, ra, w, groups, out, st); break;
-    case V_SPHERES_LBVH: case V_SPHERES_LBVH4: launch_groups<M_SPHERES_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
-    case V_TRIMESH: case V_TRIMESH4: launch_groups<M_TRIMESH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_SPHERES_LBVH: launch_groups<M_SPHERES_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_SPHERES_LBVH4: launch_groups<M_SPHERES_LBVH4, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_TRIMESH: launch_groups<M_TRIMESH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_TRIMESH4: launch_groups<M_TRIMESH4, AnyWorld>(sv, ra, w, groups, out, st); break;
     case V_FINAL: launch_groups<M_FINAL, AnyWorld>(sv, ra, w, groups, out, st); break;
-    case V_FINAL_LBVH: case V_FINAL_LBVH4: launch_groups<M_FINAL_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_FINAL_LBVH: launch_groups<M_FINAL_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_FINAL_LBVH4: launch_groups<M_FINAL_LBVH4, AnyWorld>(sv, ra, w, groups, out, st); break;
     case V_ALL: launch_groups<M_ALL, AnyWorld>(sv, ra, w, groups, out, st); break;
+    case V_ALL_LBVH4: launch_groups<M_ALL_LBVH4, AnyWorld>(sv, ra, w, groups, out, st); break;
     default: launch_groups<M_ALL_LBVH, AnyWorld>(sv, ra, w, groups, out, st); break;
     }
 }

@@ -89,11 +89,13 @@ enum PtAccel {
                               /* the reference's rectangle, box and triangle tests accept a NaN t    */
                               /* (src/ptRectangle.cu:15: a ray lying in a rectangle's plane, a       */
                               /* non-finite ray) are answered the in-order way, never by the tree.   */
-                              /* The walk reads the binary form (it measured faster on every kind of */
-                              /* scene); the two values below pick a form explicitly.                */
+                              /* The walk reads the 4-wide form where the tree's depth allows it (it  */
+                              /* measured faster on every kind of scene); the two values below pick  */
+                              /* a form explicitly.                                                  */
     PT_ACCEL_LBVH_BINARY = 2, /* PT_ACCEL_LBVH walked as built: 64-byte nodes, two child boxes each  */
-    PT_ACCEL_LBVH_WIDE = 3    /* PT_ACCEL_LBVH with every second level folded away: 128-byte nodes,  */
-                              /* four child boxes each, half the dependent node fetches per search   */
+    PT_ACCEL_LBVH_WIDE = 3    /* PT_ACCEL_LBVH with every second level folded away: 64-byte nodes,   */
+                              /* four child boxes each on a byte grid (conservative: a box is never  */
+                              /* held smaller than it is), half the dependent node fetches per search */
 };
 
 /* Which scheduler runs the radiance pipeline stages. */
