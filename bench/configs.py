@@ -64,7 +64,10 @@ def run(label, desc, nx, ny, spp, steps=2, model=None, bound="valu", **kw):
     out = {"config": label, "nx": nx, "ny": ny, "spp": spp, "kernel_ms": k, "Mpaths_per_s": nx * ny * spp / k / 1e3,
            "scene_create_s": create_s, "lbvh_nodes": int(pt.library().pt_scene_lbvh_nodes(sc._h, None, 0)),
            "schedule": st.schedule, "pipeline": st.pipeline, "launches": st.n_launches, "shapes": desc.c.n_shapes, "world": desc.c.n_world,
-           "roofline": roofline(model, bound, nx * ny * spp / (k * 1e-3))}
+           "lbvh_form": sc.lbvh_form(),
+           # a search through the 4-wide form is priced by its own replay (64-byte wide nodes), see tests/make_work_model.py
+           "roofline": roofline(model + "_wide" if model and "_lbvh" in model and sc.lbvh_form() == 4 else model, bound,
+                                nx * ny * spp / (k * 1e-3))}
     print(json.dumps(out), flush=True)
     return out
 

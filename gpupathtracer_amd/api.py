@@ -50,6 +50,7 @@ def library():
     lib.pt_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.pt_render_stats.argtypes = [C.c_void_p, P(A.PtRenderStats)]
     lib.pt_scene_lbvh_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.pt_scene_lbvh_form.argtypes = [C.c_void_p]
     lib.pt_scene_desc_builtin.argtypes = [C.c_char_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
                                           P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
@@ -372,6 +373,13 @@ class Scene:
         ts = np.empty(n, np.float32)
         _check(library().pt_trace_closest(self._h, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data))
         return ids, ts
+
+    def lbvh_form(self):
+        """0: the searches walk no library-built tree; 2: its binary nodes; 4: its 4-wide form."""
+        n = library().pt_scene_lbvh_form(self._h)
+        if n < 0:
+            _check(n)
+        return n
 
     def lbvh_nodes(self):
         """The library-built LBVH as an (n, 16) uint32 view of its 64-byte nodes (empty if none)."""

@@ -998,6 +998,12 @@ extern "C" int pt_trace_closest(PtScene* sc, const PtRay* rays, size_t n, int32_
     return rc;
 }
 
+extern "C" int pt_scene_lbvh_form(PtScene* sc)
+{
+    if (!sc) { pt::set_error("pt_scene_lbvh_form: null scene"); return PT_ERR_INVALID; }
+    return !(sc->mask & ptd::F_LBVH) ? 0 : (sc->mask & ptd::F_LBVH4) ? 4 : 2;
+}
+
 extern "C" int pt_scene_lbvh_nodes(PtScene* sc, void* nodes, size_t capacity_bytes)
 {
     if (!sc) { pt::set_error("pt_scene_lbvh_nodes: null scene"); return PT_ERR_INVALID; }

@@ -343,6 +343,10 @@ int  pt_render_progressive(PtScene* scene, const PtRenderParams* params, float* 
 /* Copies the library-built LBVH (64-byte nodes: two child boxes and two child links) to the host:
  * returns the node count, or a negative error; nodes may be NULL to query the count. */
 int  pt_scene_lbvh_nodes(PtScene* scene, void* nodes, size_t capacity_bytes);
+/* The form of the tree the scene's searches walk: 0 none (the list, or the reference's own BVHs, as they
+ * are), 2 the binary nodes pt_scene_lbvh_nodes returns, 4 the same tree with every second level folded
+ * away (PT_ACCEL_LBVH_WIDE).  Diagnostic; no counterpart in the reference. */
+int  pt_scene_lbvh_form(PtScene* scene);
 
 /* The reference's hard-coded scene builders (src/ptMain.cu:192-421) restated as
  * description factories.  name is one of "simple_spheres", "simple_light", "random",

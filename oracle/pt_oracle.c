@@ -643,7 +643,11 @@ static int medium_hit(const PtSceneDesc* sc, int m, const ray_t* r, float t0, fl
  * would take the flat walk seconds per ray); the counters, not the hit, are what this is for. */
 typedef struct { float lmin[3], lmax[3], rmin[3], rmax[3]; int32_t left, right, pad0, pad1; } tree_node;
 static const tree_node* T_nodes = NULL;
-static int T_root = 0, T_cull = 0, T_prefix = 0, T_trust = 0;
+static int T_root = 0, T_cull = 0, T_prefix = 0, T_trust = 0, T_wide = 0;
+/* wide != 0: price the search as the product's 4-wide walk of the same tree -- every second level folded
+ * away, a node holds the boxes of its up to four grandchildren (or of a child that is a leaf) and one
+ * 64-byte fetch decides four descents; tree_nodes then counts the wide nodes visited. */
+void oracle_count_tree_form(int wide) { T_wide = wide; }
 void oracle_count_through_tree(const void* nodes64, int root, int cull, int prefix, int trust_replay)
 {
     T_nodes = (const tree_node*)nodes64; T_root = root; T_cull = cull; T_prefix = prefix; T_trust = trust_replay;
@@ -670,7 +674,33 @@ static int tree_replay(const PtSceneDesc* sc, const ray_t* r, float tmin, float 
     v3 inv = V(1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z);
     FL(3);
     for (;;) {
-        if (cur >= 0) {
+        if (cur >= 0 && T_wide) {
+            const tree_node* n = &T_nodes[cur];
+            const float lim = T_cull ? best : tmax, from = T_cull ? tmin : 0.0f;
+            int kid[4], nk = 0, next = 0, have = 0;
+            const float* kmin[4]; const float* kmax[4];
+            float tnext = 0.0f;
+            EV(tree_nodes);
+            for (int side = 0; side < 2; side++) {
+                const int c = side ? n->right : n->left;
+                if (c >= 0) {
+                    const tree_node* m = &T_nodes[c];
+                    kid[nk] = m->left; kmin[nk] = m->lmin; kmax[nk] = m->lmax; nk++;
+                    kid[nk] = m->right; kmin[nk] = m->rmin; kmax[nk] = m->rmax; nk++;
+                } else {
+                    kid[nk] = c; kmin[nk] = side ? n->rmin : n->lmin; kmax[nk] = side ? n->rmax : n->lmax; nk++;
+                }
+            }
+            for (int k = 0; k < nk; k++) {
+                float t;
+                if (!tree_slab(kmin[k], kmax[k], r->o, inv, from, lim, &t)) continue;
+                if (!have) { have = 1; next = kid[k]; tnext = t; continue; }
+                FL(1);
+                if (t < tnext) { if (sp < 128) stack[sp++] = next; next = kid[k]; tnext = t; }
+                else if (sp < 128) stack[sp++] = kid[k];
+            }
+            if (have) { cur = next; continue; }
+        } else if (cur >= 0) {
             const tree_node* n = &T_nodes[cur];
             float tl, tr;
             const float lim = T_cull ? best : tmax, from = T_cull ? tmin : 0.0f;

@@ -26,19 +26,22 @@ def _load():
         _LIB.oracle_render.argtypes = [C.POINTER(A.PtSceneDesc), C.POINTER(A.PtRenderParams), C.c_void_p, C.c_int]
         _LIB.oracle_work_counters.argtypes = [C.c_void_p, C.c_int]
         _LIB.oracle_count_through_tree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _LIB.oracle_count_tree_form.argtypes = [C.c_int]
     return _LIB
 
 
-def counters(desc, nx, ny, ns, max_depth=25, threads=8, tree=None):
+def counters(desc, nx, ny, ns, max_depth=25, threads=8, tree=None, wide=False):
     """tree: None (the work of the reference's own flat walk), or (nodes, root, cull, prefix, trust): the
     library's exported LBVH as an (n, 16) uint32 array -- searches are then priced as a replay of that
     tree over world[:prefix] plus the in-order walk of the rest; trust = let the replay's hit drive the
-    path (for worlds too long for the flat walk)."""
+    path (for worlds too long for the flat walk).  wide: price the search as the 4-wide walk of that tree (every
+    second level folded away; tree_nodes then counts 64-byte wide nodes)."""
     lib = _load()
     if tree is not None:
         nodes, root, cull, prefix, trust = tree
         nodes = np.ascontiguousarray(nodes, np.uint32)
         lib.oracle_count_through_tree(nodes.ctypes.data, int(root), int(cull), int(prefix), int(trust))
+        lib.oracle_count_tree_form(1 if wide else 0)
     else:
         lib.oracle_count_through_tree(None, 0, 0, 0, 0)
     p = A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=0, shard_count=1, tile_w=8, tile_h=8)
@@ -47,6 +50,7 @@ def counters(desc, nx, ny, ns, max_depth=25, threads=8, tree=None):
     cnt = (C.c_uint64 * len(FIELDS))()
     lib.oracle_work_counters(cnt, len(FIELDS))
     lib.oracle_count_through_tree(None, 0, 0, 0, 0)
+    lib.oracle_count_tree_form(0)
     return dict(zip(FIELDS, [int(v) for v in cnt])), img
 
 

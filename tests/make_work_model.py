@@ -83,7 +83,8 @@ def main():
     out = {"convention": "FLOP = fp32 add/sub/mul/compare/min/max/div/sqrt as the reference evaluates them, no FMA credit; libm and integer "
                          "ops separate.  Flat entries: the reference's own walk (flat lists, its BVH with both children always visited).  "
                          "*_lbvh entries: the search priced as a replay of the library's exported LBVH (27 FLOP per box test), "
-                         "bytes_per_path = 64 per node visited + 64 per leaf record tested",
+                         "bytes_per_path = 64 per node visited + 64 per leaf record tested; *_lbvh_wide: the same tree walked in its "
+                         "4-wide form (every second level folded away), 64 bytes per wide node",
            "generator": "tests/make_work_model.py (oracle/pt_oracle.c built with -DPT_ORACLE_COUNT)", "configs": {}}
     for key, scene, aspect, nx, ny, ns, note in FLAT:
         desc = pt.builtin_scene(scene, aspect)
@@ -100,8 +101,14 @@ def main():
             c, _ = _oracle_stats.counters(desc, nx, ny, ns, threads=16, tree=(nodes, 0, cull, prefix, trust))
             out["configs"][key] = entry(c, note, "%dx%d at %d spp, depth 25" % (nx, ny, ns))
             print(key, json.dumps(out["configs"][key]), flush=True)
+            # the same search through the 4-wide form the product walks by default: its own node visits and bytes
+            c, _ = _oracle_stats.counters(desc, nx, ny, ns, threads=16, tree=(nodes, 0, cull, prefix, trust), wide=True)
+            out["configs"][key + "_wide"] = entry(c, note + " -- priced as the 4-wide walk (64-byte nodes of up to four child boxes)",
+                                                  "%dx%d at %d spp, depth 25" % (nx, ny, ns))
+            print(key + "_wide", json.dumps(out["configs"][key + "_wide"]), flush=True)
     else:
-        for key in ("random_lbvh", "final_lbvh", "final_lbvh_no_earth", "trimesh_lbvh"):
+        for key in ("random_lbvh", "final_lbvh", "final_lbvh_no_earth", "trimesh_lbvh",
+                    "random_lbvh_wide", "final_lbvh_wide", "final_lbvh_no_earth_wide", "trimesh_lbvh_wide"):
             if key in old:
                 out["configs"][key] = old[key]
                 print(key, "(kept: no GPU to build the tree on)", flush=True)

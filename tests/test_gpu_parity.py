@@ -340,6 +340,15 @@ def test_wavefront_scheduler_edge_cases(oracle):
     assert_bit_exact(sc2.render(64, 36, 4, pipeline=abi.PIPELINE_WAVEFRONT), sc2.render(64, 36, 4), "wavefront final+image")
 
 
+def test_tree_form_is_reported():
+    """PT_ACCEL_LBVH leaves the form of the tree to the library, which walks the 4-wide one; the explicit
+    values get what they name; a list stays a list."""
+    for accel, form in ((abi.ACCEL_LIST, 0), (abi.ACCEL_LBVH, 4), (abi.ACCEL_LBVH_BINARY, 2), (abi.ACCEL_LBVH_WIDE, 4)):
+        sc = pt.Scene(pt.builtin_scene("random", 2.0, accel=accel))
+        assert sc.lbvh_form() == form
+        assert (len(sc.lbvh_nodes()) > 0) == (form != 0)
+
+
 def test_configuration_c0_at_its_own_size(oracle):
     """BASELINE configs[0] as stated: the RTIOW random-spheres scene, 200 x 100 at 16 spp -- the case the
     reference's host-compiled path can run.  Flat list and library tree, fused and staged, against the oracle."""
