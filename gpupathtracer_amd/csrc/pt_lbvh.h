@@ -12,7 +12,7 @@ namespace pt {
 // copies.  On success *d_nodes is a hipMalloc'ed array of *n_nodes 64-byte nodes and *root is
 // the root link (>= 0 node index, < 0 ~shape).  Returns a PtError.
 // d_wide (may be null): receives the same tree folded to four children per node (64-byte LbvhNode4,
-// indexed like the binary nodes; the slots of folded-away nodes stay unused).  depth (may be null):
+// the binary nodes of even depth stored without gaps, in the binary nodes' order).  depth (may be null):
 // levels of internal nodes of the binary tree.  area_sweep: worlds of up to 32 768 leaves take the
 // shape of their tree from a surface-area sweep on the host instead of the Morton order.
 int lbvh_build(const PtSceneDesc* desc, const PtShape* d_shapes, const PtXform* d_xforms,

@@ -277,16 +277,40 @@ __device__ void wide_axis(const Box* kid, int n, int a, float& corner, uint8_t& 
     }
 }
 
-__global__ void k_emit_wide(const int* left, const int* right, const int* depth, const uint64_t* keys, const Box* leaf_boxes,
+// The wide nodes are the binary nodes of even depth; they are stored without gaps, in the binary nodes' order
+// (slot[i] = how many even-depth nodes precede node i), so that a 128-byte line holds two nodes a walk may
+// want and not one of them and a hole.  One workgroup: a chunk per thread, a scan of the chunk counts in LDS.
+__global__ __launch_bounds__(1024) void k_wide_slots(const int* depth, int n, int* slot, int* n_used)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = min(n, t * per), e = min(n, b + per);
+    int c = 0;
+    for (int i = b; i < e; i++) c += !(depth[i] & 1);
+    part[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - c;
+    for (int i = b; i < e; i++) { slot[i] = run; run += !(depth[i] & 1); }
+    if (t == 1023) *n_used = part[1023];
+}
+
+__global__ void k_emit_wide(const int* left, const int* right, const int* depth, const int* slot, const uint64_t* keys, const Box* leaf_boxes,
                             const Box* node_boxes, const PtObject* world, int n_internal, ptd::LbvhNode4* nodes)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_internal) return;
+    if (depth[i] & 1) return;                                 // folded into its parent
     ptd::LbvhNode4 nd;
     for (int a = 0; a < 3; a++) { nd.corner[a] = 0.0f; nd.step_exp[a] = 127; for (int c = 0; c < 4; c++) { nd.lo[a][c] = 255; nd.hi[a][c] = 0; } }
     nd.step_exp[3] = 0; nd.pad[0] = 0; nd.pad[1] = 0;
     for (int c = 0; c < 4; c++) nd.link[c] = ptd::LBVH4_EMPTY;
-    if (depth[i] & 1) { nodes[i] = nd; return; }              // folded into its parent: the slot stays unused
     int kids[4], n = 0;
     const int pair[2] = { left[i], right[i] };
     for (int s = 0; s < 2; s++) {
@@ -298,10 +322,10 @@ __global__ void k_emit_wide(const int* left, const int* right, const int* depth,
     for (int c = 0; c < n; c++) {
         const int k = kids[c];
         kid[c] = (k >= 0) ? node_boxes[k] : leaf_boxes[(unsigned)keys[~k]];
-        nd.link[c] = (k >= 0) ? k : ~world[(unsigned)keys[~k]].index;
+        nd.link[c] = (k >= 0) ? slot[k] : ~world[(unsigned)keys[~k]].index;
     }
     for (int a = 0; a < 3; a++) wide_axis(kid, n, a, nd.corner[a], nd.step_exp[a], nd.lo[a], nd.hi[a]);
-    nodes[i] = nd;
+    nodes[slot[i]] = nd;
 }
 
 // ---- surface-area-heuristic tree for small worlds (host) -----------------------------------------------
@@ -505,13 +529,18 @@ int lbvh_build_leaves(const PtObject* leaves, int n, float time0, float time1, c
     int h_depth = 0;
     if ((e = hipMemcpy(&h_depth, max_depth.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) { (void)hipFree(nodes); return hip_fail(e, "read depth"); }
     if (depth_out) *depth_out = h_depth + 1;                  // levels of internal nodes
+    DevBuf slot, n_used;
     if (d_wide_out) {
+        if (!slot.alloc((size_t)n_int * 4) || !n_used.alloc(4)) { (void)hipFree(nodes); set_error("lbvh_build: out of device memory"); return PT_ERR_OOM; }
+        hipLaunchKernelGGL(k_wide_slots, dim3(1), dim3(1024), 0, nullptr, depth.as<int>(), n_int, slot.as<int>(), n_used.as<int>());
+        int h_used = 0;
+        if ((e = hipMemcpy(&h_used, n_used.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) { (void)hipFree(nodes); return hip_fail(e, "read wide node count"); }
         void* wide = nullptr;
-        if ((e = hipMalloc(&wide, (size_t)n_int * sizeof(ptd::LbvhNode4))) != hipSuccess) {
+        if (h_used < 1 || h_used > n_int || (e = hipMalloc(&wide, (size_t)h_used * sizeof(ptd::LbvhNode4))) != hipSuccess) {
             (void)hipFree(nodes); set_error("lbvh_build: out of device memory"); return PT_ERR_OOM;
         }
-        hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, nullptr, left.as<int>(), right.as<int>(), depth.as<int>(), src, boxes.as<Box>(),
-                           nboxes.as<Box>(), world.as<PtObject>(), n_int, static_cast<ptd::LbvhNode4*>(wide));
+        hipLaunchKernelGGL(k_emit_wide, dim3(GI), dim3(B), 0, nullptr, left.as<int>(), right.as<int>(), depth.as<int>(), slot.as<int>(), src,
+                           boxes.as<Box>(), nboxes.as<Box>(), world.as<PtObject>(), n_int, static_cast<ptd::LbvhNode4*>(wide));
         *d_wide_out = wide;
     }
     if ((e = hipDeviceSynchronize()) != hipSuccess) {
