@@ -25,12 +25,14 @@ using namespace ptk;
 // x16 at 4/6 = 64.5/59.7 and, later, x64 at 5/6 = 191.5/185.0 (4 against 24 spilled registers: 0.2 against 1 GB
 // of scratch written per 4 spp, which HBM has to spare there; a 20 000-triangle mesh 42.2/41.5).  The
 // tree kernels keep 24 KB of stack in LDS per workgroup, so no more than 6 fit a CU whatever is asked.
+// With the 4-wide tree the final scene's kernel wants the waves more than the registers (table in the function).
 __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 {
 #ifdef PT_EXP_BLOCKS            // kernel experiments: -DPT_EXP_BLOCKS=n overrides the table below for the file being compiled
     return PT_EXP_BLOCKS;
 #endif
     const uint32_t G = F & ~F_LBVH4;                       // the form of the tree does not change the table
+    if (F == M_FINAL_LBVH4) return 6;                       // the final scene through the 4-wide tree: 3 / 4 / 5 / 6 = 59.7 / 57.0 / 56.4 / 53.6 ms (1920x1080 x64)
     return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 6 : 1;
 }
 

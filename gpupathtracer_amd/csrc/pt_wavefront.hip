@@ -277,7 +277,7 @@ __host__ __device__ constexpr int wf_min_blocks(uint32_t F)
 #ifdef PT_WF_BLOCKS             // kernel experiments
     return PT_WF_BLOCKS;
 #endif
-    return (F & ~ptk::M_CORNELL) == 0 ? 5 : 4;
+    return ((F & ~ptk::M_CORNELL) == 0 || (F & ~F_LBVH4) == ptk::M_TRIMESH) ? 5 : 4;     // 2 M triangles through the 4-wide tree x16: 4 / 5 / 6 = 188 / 147 / 177 ms
 }
 template <uint32_t F, class W>
 __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
