@@ -106,7 +106,7 @@ assert C.sizeof(PtRenderParams) == 64
 EXPORTS = [
     "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_render_device_noalloc",
     "pt_trace_closest", "pt_render_stats", "pt_render_on_devices", "pt_frame_finish_device", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
-    "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_lbvh_form", "pt_scene_desc_builtin",
+    "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_lbvh_form", "pt_scene_lbvh_wide_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",
     "pt_median_filter", "pt_median_filter_device", "pt_device_count",
     "pt_set_device", "pt_device_synchronize", "pt_device_malloc", "pt_device_free", "pt_memcpy_to_host",

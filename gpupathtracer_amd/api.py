@@ -51,6 +51,7 @@ def library():
     lib.pt_render_stats.argtypes = [C.c_void_p, P(A.PtRenderStats)]
     lib.pt_scene_lbvh_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.pt_scene_lbvh_form.argtypes = [C.c_void_p]
+    lib.pt_scene_lbvh_wide_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.pt_scene_desc_builtin.argtypes = [C.c_char_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
                                           P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
@@ -380,6 +381,18 @@ class Scene:
         if n < 0:
             _check(n)
         return n
+
+    def lbvh_wide_nodes(self):
+        """The 4-wide form of the tree as an (n, 16) uint32 view of its 64-byte nodes (empty if the scene walks none)."""
+        n = library().pt_scene_lbvh_wide_nodes(self._h, None, 0)
+        if n < 0:
+            _check(n)
+        buf = np.zeros((max(n, 0), 16), np.uint32)
+        if n > 0:
+            rc = library().pt_scene_lbvh_wide_nodes(self._h, buf.ctypes.data, buf.nbytes)
+            if rc < 0:
+                _check(rc)
+        return buf
 
     def lbvh_nodes(self):
         """The library-built LBVH as an (n, 16) uint32 view of its 64-byte nodes (empty if none)."""

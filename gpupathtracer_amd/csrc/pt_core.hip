@@ -1004,6 +1004,20 @@ extern "C" int pt_scene_lbvh_form(PtScene* sc)
     return !(sc->mask & ptd::F_LBVH) ? 0 : (sc->mask & ptd::F_LBVH4) ? 4 : 2;
 }
 
+extern "C" int pt_scene_lbvh_wide_nodes(PtScene* sc, void* nodes, size_t capacity_bytes)
+{
+    if (!sc) { pt::set_error("pt_scene_lbvh_wide_nodes: null scene"); return PT_ERR_INVALID; }
+    if (!sc->view.lbvh4) return 0;
+    size_t bytes = 0;                                         // the array was allocated for exactly its nodes
+    if (!hip_ok(hipMemPtrGetInfo(const_cast<ptd::LbvhNode4*>(sc->view.lbvh4), &bytes), "hipMemPtrGetInfo(wide nodes)")) return PT_ERR_HIP;
+    const size_t n = bytes / sizeof(ptd::LbvhNode4);
+    if (nodes) {
+        if (capacity_bytes < n * sizeof(ptd::LbvhNode4)) { pt::set_error("pt_scene_lbvh_wide_nodes: buffer too small"); return PT_ERR_INVALID; }
+        if (!hip_ok(hipMemcpy(nodes, sc->view.lbvh4, n * sizeof(ptd::LbvhNode4), hipMemcpyDeviceToHost), "hipMemcpy(wide nodes)")) return PT_ERR_HIP;
+    }
+    return (int)n;
+}
+
 extern "C" int pt_scene_lbvh_nodes(PtScene* sc, void* nodes, size_t capacity_bytes)
 {
     if (!sc) { pt::set_error("pt_scene_lbvh_nodes: null scene"); return PT_ERR_INVALID; }

@@ -347,6 +347,13 @@ int  pt_scene_lbvh_nodes(PtScene* scene, void* nodes, size_t capacity_bytes);
  * are), 2 the binary nodes pt_scene_lbvh_nodes returns, 4 the same tree with every second level folded
  * away (PT_ACCEL_LBVH_WIDE).  Diagnostic; no counterpart in the reference. */
 int  pt_scene_lbvh_form(PtScene* scene);
+/* Copies the 4-wide form of the tree to the host, as the searches read it: 64-byte nodes of 16 words --
+ * 0-2 the corner of the children's common box (floats), 3 the three step exponents (byte a: the step of axis
+ * a is 2^(byte - 127)), 4-6 the children's low planes on x, y, z (byte c = child c, in steps from the
+ * corner), 7-9 their high planes, 10-13 the links (>= 0 wide node, < 0 ~shape, 0x7fffffff none), 14-15
+ * unused.  Wide node k stands for the k-th binary node of even depth.  Returns the node count (0 when the
+ * scene walks no such form), or a negative error; nodes may be NULL to query the count.  Diagnostic. */
+int  pt_scene_lbvh_wide_nodes(PtScene* scene, void* nodes, size_t capacity_bytes);
 
 /* The reference's hard-coded scene builders (src/ptMain.cu:192-421) restated as
  * description factories.  name is one of "simple_spheres", "simple_light", "random",

@@ -340,6 +340,63 @@ def test_wavefront_scheduler_edge_cases(oracle):
     assert_bit_exact(sc2.render(64, 36, 4, pipeline=abi.PIPELINE_WAVEFRONT), sc2.render(64, 36, 4), "wavefront final+image")
 
 
+def _check_wide_tree_against_binary(sc, what):
+    """Every child box of the 4-wide form, decoded in double precision, must contain the box the binary tree
+    holds for the same child (the wide walk may enter a box needlessly, never skip one), links must agree,
+    and every wide node must be reached exactly once."""
+    b = sc.lbvh_nodes()                       # (n, 16) uint32: lmin[3] lmax[3] rmin[3] rmax[3] left right pad pad
+    w = sc.lbvh_wide_nodes()
+    assert len(b) > 0 and len(w) > 0, what
+    bf = b.view(np.float32)
+    bi = b.view(np.int32)
+    wf = w.view(np.float32)
+    wi = w.view(np.int32)
+    seen = np.zeros(len(w), bool)
+    todo = [(0, 0)]                           # (wide node, binary node): the roots
+    children = 0
+    while todo:
+        k, n = todo.pop()
+        assert not seen[k], what
+        seen[k] = True
+        kids = []                             # (binary link, lo[3], hi[3]) of up to four children
+        for side in (0, 1):
+            c = int(bi[n, 12 + side])
+            if c >= 0:
+                kids.append((int(bi[c, 12]), bf[c, 0:3], bf[c, 3:6]))
+                kids.append((int(bi[c, 13]), bf[c, 6:9], bf[c, 9:12]))
+            else:
+                kids.append((c, bf[n, 6 * side:6 * side + 3], bf[n, 6 * side + 3:6 * side + 6]))
+        corner = wf[k, 0:3].astype(np.float64)
+        step = np.array([2.0 ** (((int(w[k, 3]) >> (8 * a)) & 0xff) - 127) for a in range(3)])
+        for c, (link, lo, hi) in enumerate(kids):
+            qlo = np.array([(int(w[k, 4 + a]) >> (8 * c)) & 0xff for a in range(3)], np.float64)
+            qhi = np.array([(int(w[k, 7 + a]) >> (8 * c)) & 0xff for a in range(3)], np.float64)
+            assert np.all(corner + qlo * step <= lo.astype(np.float64)), (what, k, c)
+            assert np.all(corner + qhi * step >= hi.astype(np.float64)), (what, k, c)
+            wl = int(wi[k, 10 + c])
+            if link < 0:
+                assert wl == link, (what, k, c)
+            else:
+                assert 0 <= wl < len(w), (what, k, c)
+                todo.append((wl, link))
+            children += 1
+        for c in range(len(kids), 4):
+            assert int(wi[k, 10 + c]) == 0x7fffffff, (what, k, c)
+    assert seen.all(), what
+    return children
+
+
+def test_wide_tree_boxes_contain_the_binary_trees():
+    """The byte-grid boxes of the 4-wide tree against the float boxes of the binary tree it was folded from:
+    random spheres (surface-area tree), the final scene's boxes (Morton tree with a reference BVH's leaves),
+    a 20 000-triangle field with its flat boxes."""
+    _check_wide_tree_against_binary(pt.Scene(pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)), "random")
+    _check_wide_tree_against_binary(pt.Scene(pt.builtin_scene("final", 16 / 9, accel=abi.ACCEL_LBVH)), "final")
+    t = pt.trimesh_scene(100, 1.5)
+    t.c.accel = abi.ACCEL_LBVH
+    assert _check_wide_tree_against_binary(pt.Scene(t), "trimesh") > 20000
+
+
 def test_tree_form_is_reported():
     """PT_ACCEL_LBVH leaves the form of the tree to the library, which walks the 4-wide one; the explicit
     values get what they name; a list stays a list."""
