@@ -397,8 +397,17 @@ __device__ __forceinline__ bool box_t(const float* q, const Ray& r, const D& dx,
     t = closest;
     return any;
 }
+// A ray whose origin and direction components, and a box whose corners, lie in the range where the shortened
+// division is the whole division (rcp_refined) divides that way, with one refined reciprocal per axis for the
+// two faces on it: the same quotients bit for bit (numerators too small for that give |t| < 2^-70 either way,
+// below any t0 >= 2^-20, and are turned away by both), 36 + 60 issue slots instead of six IEEE divides' 204.
 __device__ __forceinline__ bool box_t(const float* q, const Ray& r, float t0, float t1, float& t, int& face)
 {
+    const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(q[0]), fabsf(q[1])), fmaxf(fabsf(q[2]), fabsf(q[3]))), fmaxf(fabsf(q[4]), fabsf(q[5])));
+    const bool tame = t0 >= RCP_TMIN_MIN && fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) <= RCP_BIG && big <= RCP_BIG &&
+                      fminf(fminf(ax, ay), az) >= RCP_D_MIN && fmaxf(fmaxf(ax, ay), az) <= RCP_BIG;      // false for NaN anywhere
+    if (tame) return box_t(q, r, rcp_refined(r.d.x), rcp_refined(r.d.y), rcp_refined(r.d.z), t0, t1, t, face);
     return box_t(q, r, r.d.x, r.d.y, r.d.z, t0, t1, t, face);
 }
 // Triangle::hit (src/ptTriangle.cu:28-72): Moller-Trumbore with back-face cull; the value

@@ -397,6 +397,41 @@ def test_wide_tree_boxes_contain_the_binary_trees():
     assert _check_wide_tree_against_binary(pt.Scene(t), "trimesh") > 20000
 
 
+def test_box_leaf_division_range_edges(oracle):
+    """Box leaves outside a signature world (the final scene's 400 boxes, through the reference's BVH and
+    through the library's tree in both forms) divide with the shortened sequence when ray and box lie in its
+    range and with `/` otherwise: rays on and around every edge of that range must give the oracle's hit
+    and the oracle's t bit for bit, and so must a box whose corner lies outside the range."""
+    rng = np.random.default_rng(23)
+    n = 200_000
+    rays = random_rays(rng, n, -300, 700)
+    rays["d"][: n // 2] = (rng.uniform(0, 555, (n // 2, 3)) * [1, 0.18, 1] - rays["o"][: n // 2]).astype(np.float32)   # towards the boxes
+    special_d = np.array([0.0, -0.0, 1e-45, -1e-40, 2.0 ** -31, -2.0 ** -30, 2.0 ** -30 * 1.0000001, 1e-12, -1e-9, 1e-5,
+                          2.0 ** 57, -2.0 ** 58, 2.0 ** 59, 1e30, -3e38, np.inf, -np.inf, np.nan], np.float32)
+    special_o = np.array([0.0, -0.0, 100.0, 1e-45, -1e-30, 2.0 ** 57, -2.0 ** 58 * 0.9, 2.0 ** 58, 1e25, -3e38, np.inf, np.nan], np.float32)
+    for comp, table in (("d", special_d), ("o", special_o)):
+        for _ in range(2):
+            idx = rng.integers(0, n, n // 4)
+            axis = rng.integers(0, 3, idx.size)
+            rays[comp][idx, axis] = table[rng.integers(0, table.size, idx.size)]
+    from tests._desc_tools import OwnedDesc
+    for far_corner in (False, True):
+        ids_o = None
+        for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
+            g = OwnedDesc(pt.builtin_scene("final", 16 / 9, accel=accel))
+            if far_corner:
+                box = next(sh for sh in g.lists["shapes"] if sh.type == abi.SHAPE_BOX)
+                box.p[4] = 2.0 ** 59                                 # its top, beyond the range
+            g.finalize()
+            if ids_o is None:
+                ids_o, t_o = oracle.trace_closest(g, rays)
+                assert (ids_o != abi.ID_MISS).mean() > 0.2
+            ids_g, t_g = pt.Scene(g).trace_closest(rays)
+            np.testing.assert_array_equal(ids_g, ids_o)
+            same = (bits(t_g) == bits(t_o)) | (np.isnan(t_g) & np.isnan(t_o))
+            assert same.all(), (accel, far_corner, rays[~same][:5], t_g[~same][:5], t_o[~same][:5])
+
+
 def test_tree_form_is_reported():
     """PT_ACCEL_LBVH leaves the form of the tree to the library, which walks the 4-wide one; the explicit
     values get what they name; a list stays a list."""
