@@ -264,14 +264,12 @@ __device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArg
     }
 }
 
-// One workgroup renders one group of lanes, round by round.  Every loop bound below is read from
-// LDS after a barrier, so all lanes of the workgroup take the same trips and meet at every barrier.
 // Workgroups per CU the kernel is compiled for (a register cap).  Measured on MI355X with groups of 256 /
 // 512 / 1024 lanes (Mpaths/s): rectangle scene 1024^2 x256 at 4 workgroups 7 756 / 5 702 / 3 511, at 5
 // 8 461 / 5 273 / 3 505, at 6 7 122 / 4 082 / 3 087, at 8 4 349 / 2 859 / 2 370; random spheres in the tree
 // 1920x1080 x32 at 3 1 680 / 1 906 / -, at 4 2 036 / 2 162 / 2 052, at 5 1 241 / 1 428 / 1 550; RTNW final
-// through the tree x16 at 3 1 041 / 1 233 / -, at 4 1 097 / 1 225 / 1 004, at 5 473 / 571 / 719; a
-// 1000-triangle mesh at 4 542 / 459 / 326.
+// through the tree x16 at 3 1 041 / 1 233 / -, at 4 1 097 / 1 225 / 1 004, at 5 473 / 571 / 719; 2 M
+// triangles x8 at 4 542 / 459 / 326 (all through the binary tree, before the 4-wide one).
 __host__ __device__ constexpr int wf_min_blocks(uint32_t F)
 {
 #ifdef PT_WF_BLOCKS             // kernel experiments
@@ -279,6 +277,8 @@ __host__ __device__ constexpr int wf_min_blocks(uint32_t F)
 #endif
     return ((F & ~ptk::M_CORNELL) == 0 || (F & ~F_LBVH4) == ptk::M_TRIMESH) ? 5 : 4;     // 2 M triangles through the 4-wide tree x16: 4 / 5 / 6 = 188 / 147 / 177 ms
 }
+// One workgroup renders one group of lanes, round by round.  Every loop bound below is read from
+// LDS after a barrier, so all lanes of the workgroup take the same trips and meet at every barrier.
 template <uint32_t F, class W>
 __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
 {
