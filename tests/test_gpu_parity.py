@@ -1249,7 +1249,10 @@ def _random_world(rng, base, textured=False):
     return g
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_WORLDS", "32"))))
+FUZZ_FIRST = int(os.environ.get("PT_FUZZ_FIRST", "0"))        # longer campaigns: PT_FUZZ_FIRST=n PT_FUZZ_WORLDS=m runs worlds n .. n+m-1
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_FIRST, FUZZ_FIRST + int(os.environ.get("PT_FUZZ_WORLDS", "32"))))
 def test_random_worlds_match_the_oracle(oracle, seed):
     """Closest hits and a small image for random worlds, walked in list order and through the
     library's tree: lists in arbitrary order, reference BVHs with one or mixed kinds of leaves, at
@@ -1282,7 +1285,7 @@ def test_random_worlds_match_the_oracle(oracle, seed):
         sc = pt.Scene(g)
         ids_o, t_o = oracle.trace_closest(g, rays)
         ids_g, t_g = sc.trace_closest(rays)
-        assert (ids_o != abi.ID_MISS).mean() > 0.05
+        assert (ids_o != abi.ID_MISS).mean() > 0.02            # the sparsest of 12 000 worlds: 0.04
         np.testing.assert_array_equal(ids_g, ids_o)
         np.testing.assert_array_equal(bits(t_g), bits(t_o))
         if ref is None:
@@ -1291,7 +1294,7 @@ def test_random_worlds_match_the_oracle(oracle, seed):
         assert_bit_exact(sc.render(48, 24, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "random world %d accel %d staged" % (seed, accel))
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16"))))
+@pytest.mark.parametrize("seed", range(FUZZ_FIRST, FUZZ_FIRST + int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16"))))
 def test_random_textured_worlds_through_a_lens_match_the_oracle(oracle, seed):
     """The random worlds again with image, noise and (nested) checker textures on their Lambertian,
     Isotropic and DiffuseLight materials -- so the uv of every kind of hit is read, the stale uv of
@@ -1320,6 +1323,70 @@ def test_random_textured_worlds_through_a_lens_match_the_oracle(oracle, seed):
             ref = oracle.render(g, 64, 32, 6)
         assert_bit_exact(sc.render(64, 32, 6), ref, "textured world %d accel %d" % (seed, accel))
         assert_bit_exact(sc.render(64, 32, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, "textured world %d accel %d staged" % (seed, accel))
+
+
+def _scale_world(g, k):
+    """Every length of the description times 2**k (exact in binary floating point); densities and texture
+    frequencies divided by it, so the scene is the same picture at another size."""
+    s = float(2.0 ** k)
+    lengths = {abi.SHAPE_SPHERE: (0, 1, 2, 3), abi.SHAPE_MOVING_SPHERE: (0, 1, 2, 3, 4, 5, 8), abi.SHAPE_RECT_XY: range(5),
+               abi.SHAPE_RECT_XZ: range(5), abi.SHAPE_RECT_YZ: range(5), abi.SHAPE_BOX: range(6), abi.SHAPE_TRIANGLE: range(9)}
+    for sh in g.lists["shapes"]:
+        for i in lengths[sh.type]:
+            sh.p[i] = sh.p[i] * s
+    for xf in g.lists["xforms"]:
+        if xf.type == abi.XFORM_TRANSLATE:
+            for i in range(3):
+                xf.v[i] = xf.v[i] * s
+    for nd in g.lists["bvh_nodes"]:
+        for i in range(3):
+            nd.bmin[i], nd.bmax[i] = nd.bmin[i] * s, nd.bmax[i] * s
+    for m in g.lists["media"]:
+        m.density = m.density / s
+    for t in g.lists["textures"]:
+        if t.type in (abi.TEX_CHECKER, abi.TEX_NOISE):
+            t.scale = t.scale / s
+    g.camera = [v * s if (i < 12 or i == 23) else v for i, v in enumerate(g.camera)]
+
+
+SCALES = tuple(int(v) for v in os.environ.get("PT_FUZZ_SCALES", "-33,-24,-12,12,24,40,52").split(","))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_SCALED_WORLDS", "3"))))
+@pytest.mark.parametrize("k", SCALES)
+def test_random_worlds_at_other_sizes_match_the_oracle(oracle, k, seed):
+    """The random worlds with every length multiplied by 2**k: at the small end direction components and
+    plane distances fall below the range the shortened divisions and the undecoded node walk are valid in,
+    at the large end coordinates rise above it and squares overflow -- the range tests in front of every
+    shortcut have to send those rays the long way, and the long way has to overflow as the reference does."""
+    rng = np.random.default_rng(9000 + 100 * (k + 64) + seed)
+    textured = seed % 2 == 1
+    tex = rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)
+    g = _random_world(rng, pt.builtin_scene("final", 16 / 9, earth_rgb=tex), textured=textured)
+    cam = pt.builtin_scene("simple_spheres", 2.0).c.camera
+    g.camera = [float(cam[i]) * (12.0 if i < 3 else 1.0) for i in range(24)]
+    if textured:
+        g.camera[23] = float(rng.uniform(0.01, 2.0))
+        g.scalars["ambient_type"] = 2
+    _scale_world(g, k)
+    rays = random_rays(rng, 30000, -70, 70)
+    s = np.float32(2.0 ** k)
+    rays["o"] *= s
+    rays["d"][::2] *= s                                         # every second direction at the scene's size, the others near 1
+    ref = None
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        ids_o, t_o = oracle.trace_closest(g, rays)
+        ids_g, t_g = sc.trace_closest(rays)
+        np.testing.assert_array_equal(ids_g, ids_o)
+        same = (bits(t_g) == bits(t_o)) | (np.isnan(t_g) & np.isnan(t_o))   # overflowed hits carry a NaN distance; its payload is the host's
+        assert same.all(), "%d of %d distances differ" % ((~same).sum(), same.size)
+        if ref is None:
+            ref = oracle.render(g, 48, 24, 4)
+        assert_bit_exact(sc.render(48, 24, 4), ref, "world %d times 2^%d accel %d" % (seed, k, accel))
+        assert_bit_exact(sc.render(48, 24, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "world %d times 2^%d accel %d staged" % (seed, k, accel))
 
 
 WIDE_CASES = [("random", 2.0, None), ("cornell_spheres", 1.0, None), ("simple_light", 2.0, None), ("final", 16 / 9, None),
