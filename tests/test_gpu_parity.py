@@ -859,6 +859,70 @@ def test_signature_shading_range_edges(oracle):
     check(g, 0, "lamp beyond the constants' bound")
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_FIRST", "0")), int(os.environ.get("PT_FUZZ_FIRST", "0")) + int(os.environ.get("PT_FUZZ_ROOMS", "24"))))
+def test_random_rooms_match_the_oracle(oracle, seed):
+    """Worlds with the Cornell box's list of kinds (five walls, a lamp, two turned boxes) and everything else
+    drawn at random -- extents, planes, flips, turns, colours, lamp, overall size, camera, lens: the
+    rectangle-scene kernels (compiled-in walk, face table, shortened divisions) on scenes other than the one
+    they were tuned on, under every schedule and on both pipelines."""
+    from tests._desc_tools import OwnedDesc, look_at_camera
+    rng = np.random.default_rng(20000 + seed)
+    g = OwnedDesc(pt.builtin_scene("cornell", 1.0))
+    size = float(2.0 ** int(rng.integers(-14, 15))) if seed % 3 == 0 else 1.0
+    for sh in g.lists["shapes"]:
+        pairs = 3 if sh.type == abi.SHAPE_BOX else 2
+        lo = [sh.p[i] * rng.uniform(0.7, 1.3) + rng.uniform(-40, 40) for i in (range(3) if pairs == 3 else (0, 2))]
+        ext = [abs(sh.p[i + 3] - sh.p[i]) if pairs == 3 else abs(sh.p[2 * i + 1] - sh.p[2 * i]) for i in range(pairs)]
+        ext = [e * rng.uniform(0.6, 1.5) + 1.0 for e in ext]
+        if pairs == 3:
+            for i in range(3):
+                sh.p[i], sh.p[i + 3] = lo[i] * size, (lo[i] + ext[i]) * size
+        else:
+            for i in range(2):
+                sh.p[2 * i], sh.p[2 * i + 1] = lo[i] * size, (lo[i] + ext[i]) * size
+            sh.p[4] = (sh.p[4] + rng.uniform(-30, 30)) * size
+            if rng.random() < 0.25 and sh is not g.lists["shapes"][g.lists["lights"][0]]:
+                sh.flags ^= abi.FLIP_NORMAL
+    for xf in g.lists["xforms"]:
+        if xf.type == abi.XFORM_TRANSLATE:
+            for i in range(3):
+                xf.v[i] = (xf.v[i] + rng.uniform(-60, 60)) * size
+        else:
+            if rng.random() < 0.8:
+                ang = np.float32(rng.uniform(-np.pi, np.pi))
+                xf.v[0], xf.v[1] = float(np.sin(ang, dtype=np.float32)), float(np.cos(ang, dtype=np.float32))
+            else:                                               # quarter turns, exactly
+                xf.v[0], xf.v[1] = [(0.0, 1.0), (1.0, 0.0), (-1.0, 0.0), (0.0, -1.0)][int(rng.integers(0, 4))]
+    for t in g.lists["textures"]:
+        if t.type == abi.TEX_CONSTANT:
+            for i in range(3):
+                t.color[i] = 0.0 if rng.random() < 0.1 else float(np.float32(rng.uniform(0.02, 1.0) * (15.0 if t.color[0] > 1 else 1.0)))
+    frm = rng.uniform(50, 500, 3); frm[2] = rng.uniform(-900, 200)
+    to = rng.uniform(150, 400, 3)
+    aperture = 0.0 if seed % 2 == 0 else float(rng.uniform(0.1, 20.0))
+    g.camera = look_at_camera(frm * size, to * size, (0, 1, 0), rng.uniform(25, 75), 1.0, aperture * size, 10.0 * size)
+    lamp = g.lists["shapes"][g.lists["lights"][0]]
+    if seed % 4 >= 2:                                           # a lamp as large as the ceiling: few paths end in the dark
+        lamp.p[0], lamp.p[1], lamp.p[2], lamp.p[3] = lamp.p[0] - 150 * size, lamp.p[1] + 150 * size, lamp.p[2] - 150 * size, lamp.p[3] + 150 * size
+    sky = seed % 8 == 7
+    if sky:
+        g.scalars["ambient_type"] = 2                           # paths that leave the room bring light in: not a rectangle-scene kernel's case
+    g.finalize()
+    sc = pt.Scene(g)
+    depth = int(rng.choice([1, 2, 5, 25]))
+    ref = oracle.render(g, 56, 56, 6, depth)
+    for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
+        assert_bit_exact(sc.render(56, 56, 6, depth, schedule=schedule), ref, "room %d schedule %d" % (seed, schedule))
+    assert sc.stats().signature_walk == (0 if sky else 1)
+    assert_bit_exact(sc.render(56, 56, 6, depth, pipeline=abi.PIPELINE_WAVEFRONT), ref, "room %d staged" % seed)
+    rays = np.concatenate([oracle.record_rays(g, 48, 48, 6, 20000), random_rays(rng, 20000, -100, 700)])
+    rays["o"][-20000:] *= np.float32(size)
+    ids_o, t_o = oracle.trace_closest(g, rays)
+    ids_g, t_g = sc.trace_closest(rays)
+    np.testing.assert_array_equal(ids_g, ids_o)
+    np.testing.assert_array_equal(bits(t_g), bits(t_o))
+
+
 @pytest.mark.parametrize("which", ["random", "cornell_spheres", "trimesh", "trimesh_big"])
 def test_shared_walk_schedule_bit_exact(oracle, which):
     """PT_SCHEDULE_WALK: the wave shares the tree search one step at a time and lanes whose search has
