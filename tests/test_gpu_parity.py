@@ -923,6 +923,89 @@ def test_random_rooms_match_the_oracle(oracle, seed):
     np.testing.assert_array_equal(bits(t_g), bits(t_o))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_FIRST", "0")), int(os.environ.get("PT_FUZZ_FIRST", "0")) + int(os.environ.get("PT_FUZZ_SPHERE_WORLDS", "12"))))
+def test_random_sphere_worlds_match_the_oracle(oracle, seed):
+    """Worlds of the RTIOW scene's kinds (static and moving spheres over its Lambertian, Metal and Dielectric
+    materials and its checker), everything else drawn at random: the sphere-scene kernels -- both tree forms,
+    every schedule including the shared walk, both pipelines -- on scenes other than the one they were tuned on."""
+    from tests._desc_tools import OwnedDesc
+    from gpupathtracer_amd import _abi as A
+    rng = np.random.default_rng(30000 + seed)
+    g = OwnedDesc(pt.builtin_scene("random", 2.0))
+    n_mat = len(g.lists["materials"])
+    shapes = [g.lists["shapes"][0]]                             # the ground
+    spread = float(rng.choice([3.0, 11.0, 40.0]))
+    for _ in range(int(rng.integers(3, 400))):
+        c = rng.uniform(-spread, spread, 3).astype(np.float32)
+        c[1] = np.float32(rng.uniform(0.0, 2.0))
+        r = np.float32(rng.uniform(0.05, 1.5) if rng.random() < 0.9 else rng.uniform(2.0, 6.0))
+        s = A.PtShape(type=abi.SHAPE_SPHERE, flags=0, material=int(rng.integers(0, n_mat)), xform_first=0, xform_count=0, tri_uv=-1)
+        if rng.random() < 0.5:
+            s.type = abi.SHAPE_MOVING_SPHERE
+            c1 = (c + rng.uniform(-1, 1, 3) * rng.uniform(0, 2)).astype(np.float32)
+            vals = [c[0], c[1], c[2], c1[0], c1[1], c1[2], 0.0, 1.0, r]
+        else:
+            vals = [c[0], c[1], c[2], r]
+        for i, v in enumerate(vals):
+            s.p[i] = float(v)
+        shapes.append(s)
+    g.lists["shapes"] = shapes
+    g.lists["world"] = [A.PtObject(type=abi.OBJ_SHAPE, index=int(i)) for i in rng.permutation(len(shapes))]
+    if seed % 2:
+        g.camera[23] = float(rng.uniform(0.01, 0.3))
+    ref = None
+    for accel in (abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        if ref is None:
+            ref = oracle.render(g, 64, 32, 4)
+            rays = np.concatenate([oracle.record_rays(g, 48, 24, 4, 20000), random_rays(rng, 20000, -spread, spread)])
+            ids_o, t_o = oracle.trace_closest(g, rays)
+        for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL, abi.SCHEDULE_WALK):
+            assert_bit_exact(sc.render(64, 32, 4, schedule=schedule), ref, "sphere world %d accel %d schedule %d" % (seed, accel, schedule))
+        assert_bit_exact(sc.render(64, 32, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "sphere world %d accel %d staged" % (seed, accel))
+        ids_g, t_g = sc.trace_closest(rays)
+        np.testing.assert_array_equal(ids_g, ids_o)
+        np.testing.assert_array_equal(bits(t_g), bits(t_o))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_FIRST", "0")), int(os.environ.get("PT_FUZZ_FIRST", "0")) + int(os.environ.get("PT_FUZZ_TRIANGLE_WORLDS", "8"))))
+def test_random_triangle_worlds_match_the_oracle(oracle, seed):
+    """The tessellated field in its enclosure with every vertex moved at random (the triangles come apart,
+    overlap and stand on edge) and the whole scene at another size now and then: the triangle kernels --
+    both tree forms, every schedule, both pipelines -- against the oracle's walk of the list."""
+    from tests._desc_tools import OwnedDesc
+    rng = np.random.default_rng(40000 + seed)
+    g = OwnedDesc(pt.trimesh_scene(int(rng.integers(3, 36)), 1.0))
+    size = float(2.0 ** int(rng.integers(-10, 11))) if seed % 3 == 0 else 1.0
+    amount = float(rng.choice([0.5, 5.0, 40.0]))
+    for sh in g.lists["shapes"]:
+        if sh.type == abi.SHAPE_TRIANGLE:
+            for i in range(9):
+                sh.p[i] = (sh.p[i] + float(rng.normal()) * amount) * size
+        else:
+            for i in range(5):
+                sh.p[i] = sh.p[i] * size
+    g.camera = [v * size if (i < 12 or i == 23) else v for i, v in enumerate(g.camera)]
+    ref = None
+    for accel in (abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        if ref is None:
+            ref = oracle.render(g, 48, 48, 4)
+            rays = np.concatenate([oracle.record_rays(g, 40, 40, 4, 20000), random_rays(rng, 20000, -100, 700)])
+            rays["o"][-20000:] *= np.float32(size)
+            ids_o, t_o = oracle.trace_closest(g, rays)
+        for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL, abi.SCHEDULE_WALK):
+            assert_bit_exact(sc.render(48, 48, 4, schedule=schedule), ref, "triangle world %d accel %d schedule %d" % (seed, accel, schedule))
+        assert_bit_exact(sc.render(48, 48, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "triangle world %d accel %d staged" % (seed, accel))
+        ids_g, t_g = sc.trace_closest(rays)
+        np.testing.assert_array_equal(ids_g, ids_o)
+        np.testing.assert_array_equal(bits(t_g), bits(t_o))
+
+
 @pytest.mark.parametrize("which", ["random", "cornell_spheres", "trimesh", "trimesh_big"])
 def test_shared_walk_schedule_bit_exact(oracle, which):
     """PT_SCHEDULE_WALK: the wave shares the tree search one step at a time and lanes whose search has
@@ -1175,13 +1258,15 @@ def test_a_ray_leaving_a_triangle_hits_it_again_through_the_tree(oracle):
     np.testing.assert_array_equal(bits(t_g), bits(t_o))
 
 
-def _random_world(rng, base, textured=False):
+def _random_world(rng, base, textured=False, final_kinds=False):
     """A random world over the materials of the RTNW final scene: spheres, moving spheres, boxes,
     rectangles (some flipped, some wrapped boxes), triangles, an optional reference BVH at the head of the
     list or later in it (median splits, boxes = unions of the leaves' bounds), optional media.
     textured: `base` carries an image texture; checker (of image and noise, and nested), noise and image
     textures are put on Lambertian, Isotropic and DiffuseLight materials, and a few small moving
-    spheres sit near the origin, where their uv (asinf of the world-space y) is finite."""
+    spheres sit near the origin, where their uv (asinf of the world-space y) is finite.
+    final_kinds: only what the RTNW final scene is made of -- no triangles, no wrapped boxes, at most one
+    un-flipped rectangle as the light shape -- so the world runs on the kernels compiled for that scene."""
     from tests._desc_tools import OwnedDesc
     from gpupathtracer_amd import _abi as A
     g = OwnedDesc(base)
@@ -1227,6 +1312,8 @@ def _random_world(rng, base, textured=False):
         c = rng.uniform(-50, 50, 3).astype(np.float32)
         r = np.float32(rng.uniform(1, 12))
         k = rng.integers(0, 7)
+        if final_kinds and k in (3, 6):
+            k = int(rng.choice([0, 1, 2, 4]))
         if k == 6:
             v = (c[None, :] + rng.uniform(-12, 12, (3, 3))).astype(np.float32)
             i = add(abi.SHAPE_TRIANGLE, list(v.reshape(-1)))
@@ -1302,9 +1389,9 @@ def _random_world(rng, base, textured=False):
     g.lists["media"], g.lists["world"] = media, entries
     g.lists["lights"] = []
     g.scalars["lights_is_list"] = 0
-    lamps = [i for i, sh in enumerate(shapes) if sh.type == abi.SHAPE_RECT_XZ and sh.xform_count == 0]
+    lamps = [i for i, sh in enumerate(shapes) if sh.type == abi.SHAPE_RECT_XZ and sh.xform_count == 0 and not (final_kinds and sh.flags & abi.FLIP_NORMAL)]
     balls = [i for i, sh in enumerate(shapes) if sh.type == abi.SHAPE_SPHERE]
-    mode = int(rng.integers(0, 3))                             # no light shapes / one rectangle / a list of two
+    mode = int(rng.integers(0, 2 if final_kinds else 3))       # no light shapes / one rectangle / a list of two
     if mode == 1 and lamps:
         g.lists["lights"] = [lamps[0]]
     elif mode == 2 and lamps and balls:
@@ -1356,6 +1443,36 @@ def test_random_worlds_match_the_oracle(oracle, seed):
             ref = oracle.render(g, 48, 24, 4)
         assert_bit_exact(sc.render(48, 24, 4), ref, "random world %d accel %d" % (seed, accel))
         assert_bit_exact(sc.render(48, 24, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "random world %d accel %d staged" % (seed, accel))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_FIRST, FUZZ_FIRST + int(os.environ.get("PT_FUZZ_FINAL_WORLDS", "16"))))
+def test_random_worlds_of_the_final_scenes_kinds_match_the_oracle(oracle, seed):
+    """The random worlds restricted to what the RTNW final scene is made of (spheres, moving spheres, boxes,
+    rectangles, a reference BVH, a medium; its noise and image textures; one rectangle lamp): these run on the
+    kernels compiled for that scene rather than on the all-features ones.  Both tree forms and the reference's
+    tree as is, every schedule, both pipelines, through a lens half of the time."""
+    rng = np.random.default_rng(7000 + seed)
+    tex = rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)
+    g = _random_world(rng, pt.builtin_scene("final", 16 / 9, earth_rgb=tex), final_kinds=True)
+    assert not any(sh.type == abi.SHAPE_TRIANGLE or sh.xform_count for sh in g.lists["shapes"])
+    cam = pt.builtin_scene("simple_spheres", 2.0).c.camera
+    g.camera = [float(cam[k]) * (12.0 if k < 3 else 1.0) for k in range(24)]
+    g.camera[23] = 0.0 if seed % 2 == 0 else float(rng.uniform(0.01, 2.0))
+    rays = random_rays(rng, 30000, -70, 70)
+    ref = None
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH_BINARY, abi.ACCEL_LBVH_WIDE):
+        g.scalars["accel"] = accel
+        g.finalize()
+        sc = pt.Scene(g)
+        ids_o, t_o = oracle.trace_closest(g, rays)
+        ids_g, t_g = sc.trace_closest(rays)
+        np.testing.assert_array_equal(ids_g, ids_o)
+        np.testing.assert_array_equal(bits(t_g), bits(t_o))
+        if ref is None:
+            ref = oracle.render(g, 64, 32, 6)
+        for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
+            assert_bit_exact(sc.render(64, 32, 6, schedule=schedule), ref, "final-kind world %d accel %d schedule %d" % (seed, accel, schedule))
+        assert_bit_exact(sc.render(64, 32, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, "final-kind world %d accel %d staged" % (seed, accel))
 
 
 @pytest.mark.parametrize("seed", range(FUZZ_FIRST, FUZZ_FIRST + int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16"))))
