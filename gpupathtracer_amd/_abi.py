@@ -12,6 +12,7 @@ AMBIENT_NONE, AMBIENT_CONSTANT, AMBIENT_SKY = 0, 1, 2
 ACCEL_LIST, ACCEL_LBVH, ACCEL_LBVH_BINARY, ACCEL_LBVH_WIDE = 0, 1, 2, 3
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL, SCHEDULE_WALK = 0, 1, 2, 3
+KERNELS_RECTANGLES, KERNELS_SPHERES, KERNELS_TRIANGLES, KERNELS_FINAL, KERNELS_ALL = 1, 2, 3, 4, 5
 STREAM_KEEP_AMBIENT_COLOR = 1
 ID_MISS = -1
 ID_MEDIUM_BASE = 0x40000000
@@ -94,7 +95,7 @@ class PtRay(C.Structure):
 class PtRenderStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("n_launches", C.c_int32),
                 ("pipeline", C.c_int32), ("paths", C.c_uint64), ("schedule", C.c_int32), ("signature_walk", C.c_int32),
-                ("reserved", C.c_uint64 * 3)]
+                ("kernel_family", C.c_int32), ("reserved0", C.c_int32), ("reserved", C.c_uint64 * 2)]
 
 
 assert C.sizeof(PtShape) == 64

@@ -294,6 +294,7 @@ class RenderStats:
         self.paths = int(s.paths)
         self.schedule = int(s.schedule)
         self.signature_walk = int(s.signature_walk)
+        self.kernel_family = int(s.kernel_family)
 
 
 def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0,

@@ -39,6 +39,17 @@ const struct { int variant; uint32_t mask; } k_variants[] = {
     { V_FINAL, M_FINAL }, { V_FINAL_LBVH, M_FINAL_LBVH }, { V_ALL, M_ALL }, { V_ALL_LBVH, M_ALL_LBVH },
     { V_SPHERES_LBVH4, M_SPHERES_LBVH4 }, { V_TRIMESH4, M_TRIMESH4 }, { V_FINAL_LBVH4, M_FINAL_LBVH4 }, { V_ALL_LBVH4, M_ALL_LBVH4 } };
 
+int kernel_family(int variant)
+{
+    switch (variant) {
+    case V_CORNELL: case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: return PT_KERNELS_RECTANGLES;
+    case V_SPHERES: case V_SPHERES_LBVH: case V_SPHERES_LBVH4: return PT_KERNELS_SPHERES;
+    case V_TRIMESH: case V_TRIMESH4: return PT_KERNELS_TRIANGLES;
+    case V_FINAL: case V_FINAL_LBVH: case V_FINAL_LBVH4: return PT_KERNELS_FINAL;
+    default: return PT_KERNELS_ALL;
+    }
+}
+
 int pick_variant(uint32_t scene_mask)
 {
     for (const auto& v : k_variants)
@@ -726,7 +737,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     const bool whole_world_in_tree = (sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1;
     if (p->schedule == PT_SCHEDULE_WALK ||
         (p->schedule == PT_SCHEDULE_AUTO && whole_world_in_tree && ((sc->mask & ptd::F_TRIANGLE) || ((sc->variant == V_SPHERES_LBVH || sc->variant == V_SPHERES_LBVH4) && sc->view.n_world >= 64)))) ra.refill = 2;   // a 7-sphere room: TILES 47.9, WALK 50.8
-    ra.walk_wait = 48;
+    ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
     // One render of a scene at a time: the pixel-slot counter and the timing events belong to the
@@ -737,6 +748,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->last = PtRenderStats{};
+    sc->last.kernel_family = kernel_family(sc->variant);
     if (p->pipeline == PT_PIPELINE_WAVEFRONT && (ra.seed_offset != 0 || ra.raw_sum)) {
         pt::set_error("render: sample batches run on the fused pipeline"); return PT_ERR_UNSUPPORTED;
     }
@@ -850,6 +862,7 @@ extern "C" int pt_render_pass(PtScene* sc, const PtRenderParams* p, void* d_accu
         !hip_ok(hipMemsetAsync(d_accum, 0, pt_accum_bytes(p->nx, p->ny), st), "hipMemsetAsync(accumulators)")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->last = PtRenderStats{};
+    sc->last.kernel_family = kernel_family(sc->variant);
     if (ra.n_wave_tiles > 0)
         launch_pass(launch_variant(sc, ra), sc->view, ra, static_cast<PtAccumPixel*>(d_accum), first_sample, out, sc->bad_resume_dev, st);
     if (!hip_ok(hipGetLastError(), "render pass launch")) return PT_ERR_HIP;

@@ -227,6 +227,16 @@ typedef struct PtRenderParams {
 typedef struct PtRay { float o[3]; float d[3]; float time; uint32_t seed; } PtRay;   /* 32 bytes */
 
 /* Timings of the most recent pt_render*/
+/* The radiance kernels are compiled once per family of scenes; a scene runs on the first family that
+ * covers every kind of shape, material, texture and light it holds. */
+typedef enum PtKernelFamily {
+    PT_KERNELS_RECTANGLES = 1, /* rectangles, boxes, wrappers, light shapes: the Cornell box's kinds (src/ptMain.cu:300-348) */
+    PT_KERNELS_SPHERES    = 2, /* static and moving spheres, metal, glass, checker, sky: the RTIOW scene's (src/ptMain.cu:192-243) */
+    PT_KERNELS_TRIANGLES  = 3, /* triangles and rectangles in the library's tree, light shapes                */
+    PT_KERNELS_FINAL      = 4, /* the RTNW final scene's kinds (src/ptMain.cu:350-421)                      */
+    PT_KERNELS_ALL        = 5  /* every feature                                                             */
+} PtKernelFamily;
+
 typedef struct PtRenderStats {
     float    kernel_ms;      /* HIP-event time of the radiance kernel(s) on their stream */
     float    total_ms;       /* HIP-event time of the whole call on that stream          */
@@ -235,7 +245,9 @@ typedef struct PtRenderStats {
     uint64_t paths;          /* camera samples traced by this call (this shard only)      */
     int32_t  schedule;       /* PtSchedule the fused pipeline ran (TILES or REFILL), else 0 */
     int32_t  signature_walk; /* 1 when the world list matched a compiled-in signature (straight-line walk) */
-    uint64_t reserved[3];
+    int32_t  kernel_family;  /* PtKernelFamily: which compiled specialisation of the radiance kernels ran */
+    int32_t  reserved0;
+    uint64_t reserved[2];
 } PtRenderStats;
 
 typedef struct PtScene PtScene;

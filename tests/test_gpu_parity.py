@@ -432,6 +432,24 @@ def test_box_leaf_division_range_edges(oracle):
             assert same.all(), (accel, far_corner, rays[~same][:5], t_g[~same][:5], t_o[~same][:5])
 
 
+def test_kernel_family_is_reported():
+    """PtRenderStats.kernel_family: the benchmark configurations run on the kernels compiled for their kinds,
+    a scene that mixes kinds on the all-features ones."""
+    expect = {"cornell": abi.KERNELS_RECTANGLES, "random": abi.KERNELS_SPHERES, "simple_spheres": abi.KERNELS_SPHERES,
+              "final": abi.KERNELS_FINAL, "simple_light": abi.KERNELS_ALL}
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+        for name, family in expect.items():
+            sc = pt.Scene(pt.builtin_scene(name, 1.0, accel=accel))
+            if name == "cornell" and accel == abi.ACCEL_LBVH:      # no rectangle-scene kernel walks a tree
+                family = abi.KERNELS_ALL
+            for pipeline in (abi.PIPELINE_FUSED, abi.PIPELINE_WAVEFRONT):
+                sc.render(16, 16, 1, pipeline=pipeline)
+                assert sc.stats().kernel_family == family, (name, accel, pipeline)
+    sc = pt.Scene(pt.trimesh_scene(6, 1.0))
+    sc.render(16, 16, 1)
+    assert sc.stats().kernel_family == abi.KERNELS_TRIANGLES
+
+
 def test_tree_form_is_reported():
     """PT_ACCEL_LBVH leaves the form of the tree to the library, which walks the 4-wide one; the explicit
     values get what they name; a list stays a list."""
@@ -914,6 +932,7 @@ def test_random_rooms_match_the_oracle(oracle, seed):
     for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
         assert_bit_exact(sc.render(56, 56, 6, depth, schedule=schedule), ref, "room %d schedule %d" % (seed, schedule))
     assert sc.stats().signature_walk == (0 if sky else 1)
+    assert sc.stats().kernel_family == (abi.KERNELS_ALL if sky else abi.KERNELS_RECTANGLES)
     assert_bit_exact(sc.render(56, 56, 6, depth, pipeline=abi.PIPELINE_WAVEFRONT), ref, "room %d staged" % seed)
     rays = np.concatenate([oracle.record_rays(g, 48, 48, 6, 20000), random_rays(rng, 20000, -100, 700)])
     rays["o"][-20000:] *= np.float32(size)
@@ -965,6 +984,7 @@ def test_random_sphere_worlds_match_the_oracle(oracle, seed):
         for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL, abi.SCHEDULE_WALK):
             assert_bit_exact(sc.render(64, 32, 4, schedule=schedule), ref, "sphere world %d accel %d schedule %d" % (seed, accel, schedule))
         assert_bit_exact(sc.render(64, 32, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "sphere world %d accel %d staged" % (seed, accel))
+        assert sc.stats().kernel_family == abi.KERNELS_SPHERES
         ids_g, t_g = sc.trace_closest(rays)
         np.testing.assert_array_equal(ids_g, ids_o)
         np.testing.assert_array_equal(bits(t_g), bits(t_o))
@@ -1001,6 +1021,7 @@ def test_random_triangle_worlds_match_the_oracle(oracle, seed):
         for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL, abi.SCHEDULE_WALK):
             assert_bit_exact(sc.render(48, 48, 4, schedule=schedule), ref, "triangle world %d accel %d schedule %d" % (seed, accel, schedule))
         assert_bit_exact(sc.render(48, 48, 4, pipeline=abi.PIPELINE_WAVEFRONT), ref, "triangle world %d accel %d staged" % (seed, accel))
+        assert sc.stats().kernel_family == abi.KERNELS_TRIANGLES
         ids_g, t_g = sc.trace_closest(rays)
         np.testing.assert_array_equal(ids_g, ids_o)
         np.testing.assert_array_equal(bits(t_g), bits(t_o))
@@ -1473,6 +1494,7 @@ def test_random_worlds_of_the_final_scenes_kinds_match_the_oracle(oracle, seed):
         for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
             assert_bit_exact(sc.render(64, 32, 6, schedule=schedule), ref, "final-kind world %d accel %d schedule %d" % (seed, accel, schedule))
         assert_bit_exact(sc.render(64, 32, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, "final-kind world %d accel %d staged" % (seed, accel))
+        assert sc.stats().kernel_family == abi.KERNELS_FINAL
 
 
 @pytest.mark.parametrize("seed", range(FUZZ_FIRST, FUZZ_FIRST + int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16"))))
