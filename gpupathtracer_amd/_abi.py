@@ -11,7 +11,7 @@ OBJ_SHAPE, OBJ_MEDIUM, OBJ_BVH = 1, 2, 3
 AMBIENT_NONE, AMBIENT_CONSTANT, AMBIENT_SKY = 0, 1, 2
 ACCEL_LIST, ACCEL_LBVH, ACCEL_LBVH_BINARY, ACCEL_LBVH_WIDE = 0, 1, 2, 3
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
-SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL, SCHEDULE_WALK = 0, 1, 2, 3
+SCHEDULE_AUTO, SCHEDULE_TILES, SCHEDULE_REFILL, SCHEDULE_WALK, SCHEDULE_CHUNKS = 0, 1, 2, 3, 4
 KERNELS_RECTANGLES, KERNELS_SPHERES, KERNELS_TRIANGLES, KERNELS_FINAL, KERNELS_ALL = 1, 2, 3, 4, 5
 STREAM_KEEP_AMBIENT_COLOR = 1
 ID_MISS = -1
@@ -85,7 +85,7 @@ class PtRenderParams(C.Structure):
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32),
                 ("pipeline", C.c_int32), ("schedule", C.c_int32), ("batch_index", C.c_int32), ("batch_count", C.c_int32),
-                ("raw_sum", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("raw_sum", C.c_int32), ("chunk_samples", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class PtRay(C.Structure):

@@ -83,6 +83,14 @@ void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float
 #undef PT_LAUNCH
 }
 
+void launch_chunks(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault,
+                   hipStream_t st)
+{
+#define PT_LAUNCH(F, W) FusedLaunch<F, W>::chunks(sv, ra, out, words, rng_states, fault, st)
+    PT_FOR_VARIANT(variant, PT_LAUNCH)
+#undef PT_LAUNCH
+}
+
 void launch_pass(int variant, const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume,
                  hipStream_t st)
 {
@@ -646,6 +654,7 @@ extern "C" void pt_scene_destroy(PtScene* sc)
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->bad_resume_host) (void)hipHostFree(sc->bad_resume_host);
     if (sc->wf_workspace) (void)hipFree(sc->wf_workspace);
+    if (sc->chunk_workspace) (void)hipFree(sc->chunk_workspace);
     if (sc->staging) (void)hipFree(sc->staging);
     if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
     if (sc->ev_k0) (void)hipEventDestroy(sc->ev_k0);
@@ -703,6 +712,8 @@ namespace {
 // Cornell 1024^2 at 512 spp, with / without control flow: whole frame 47.7 / 48.6 ms, half 28.6 / 28.4,
 // a quarter 19.7 / 19.2, an eighth 15.1 / 14.2: the two meet at eight wave tiles per SIMD.
 constexpr int FLAT_UP_TO_WAVES = 8 * 1024;
+constexpr int CHUNK_WAVE_SLOTS = 256 * 4 * 6;      // wave slots of the GPU at the rectangle-scene kernels' six waves per SIMD
+constexpr int CHUNK_MIN_SAMPLES = 64;             // AUTO cuts no finer: a chunk's start and end cost a few microseconds
 int launch_variant(const PtScene* sc, const RenderArgs& ra)
 {
     if (sc->variant != V_CORNELL_WORLD) return sc->variant;
@@ -720,8 +731,13 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         pt::set_error("render: unknown pipeline"); return PT_ERR_INVALID;
     }
     if (p->schedule != PT_SCHEDULE_AUTO && p->schedule != PT_SCHEDULE_TILES && p->schedule != PT_SCHEDULE_REFILL &&
-        p->schedule != PT_SCHEDULE_WALK) {
+        p->schedule != PT_SCHEDULE_WALK && p->schedule != PT_SCHEDULE_CHUNKS) {
         pt::set_error("render: unknown schedule"); return PT_ERR_INVALID;
+    }
+    if (p->chunk_samples < 0) { pt::set_error("render: chunk_samples is negative"); return PT_ERR_INVALID; }
+    if (p->schedule == PT_SCHEDULE_CHUNKS && no_alloc) {
+        pt::set_error("pt_render_device_noalloc: PT_SCHEDULE_CHUNKS keeps per-pixel state in memory the scene allocates; use another schedule");
+        return PT_ERR_UNSUPPORTED;
     }
     if (p->schedule == PT_SCHEDULE_WALK && !((sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1)) {
         pt::set_error("render: PT_SCHEDULE_WALK needs the whole world in the library's LBVH and a bounce limit of at least 1");
@@ -737,6 +753,28 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     const bool whole_world_in_tree = (sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1;
     if (p->schedule == PT_SCHEDULE_WALK ||
         (p->schedule == PT_SCHEDULE_AUTO && whole_world_in_tree && ((sc->mask & ptd::F_TRIANGLE) || ((sc->variant == V_SPHERES_LBVH || sc->variant == V_SPHERES_LBVH4) && sc->view.n_world >= 64)))) ra.refill = 2;   // a 7-sphere room: TILES 47.9, WALK 50.8
+    // TILES in chunks of samples (k_render_chunks): asked for, or under AUTO for the kernels it was measured to pay on,
+    // when the tiles are few for the GPU's 6 144 wave slots and the samples many: the frame is then cut into about 32
+    // rounds of work items.  Measured (MI355X, kernel ms, TILES / CHUNKS): rectangle scene 1024^2 x4096 241.1 / 211.6
+    // (12 chunks of 342 samples; chunks of 64 / 128 / 256 / 512 / 1024: 217.7 / 212.0 / 211.8 / 213.3 / 222.7), x512
+    // 31.7 / 29.3; half of that frame (8 192 tiles, 1.3 rounds) 18.3 / 19.7 and an eighth 9.10 / 11.0, so launches of
+    // less than two rounds stay with TILES; RTNW final through the 4-wide tree 1920x1080 x256 205.3 / 192.1; seven
+    // spheres in the room (list walk) 1024^2 x1024 302.9 / 325.4: its chunk kernel compiles 10 % slower, so it stays too.
+    ra.chunk_samples = ra.n_chunks = 0;
+    const bool chunks_pay = (sc->variant == V_CORNELL_WORLD || sc->variant == V_FINAL_LBVH4 || sc->variant == V_FINAL_LBVH) &&
+                            ra.n_wave_tiles >= 2 * CHUNK_WAVE_SLOTS;
+    if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill == 0 && ra.n_wave_tiles > 0 && !no_alloc &&
+        (p->schedule == PT_SCHEDULE_CHUNKS || (p->schedule == PT_SCHEDULE_AUTO && chunks_pay))) {
+        int chunk = p->chunk_samples;
+        if (chunk == 0) {
+            const long long want_items = 32LL * CHUNK_WAVE_SLOTS;
+            const int pieces = (int)std::min<long long>((want_items + ra.n_wave_tiles - 1) / ra.n_wave_tiles, std::max(1, p->ns / CHUNK_MIN_SAMPLES));
+            chunk = (p->ns + pieces - 1) / std::max(1, pieces);
+        }
+        chunk = std::max(1, std::min(chunk, std::max(1, p->ns)));
+        const int pieces = std::max(1, (p->ns + chunk - 1) / chunk);
+        if (p->schedule == PT_SCHEDULE_CHUNKS || pieces >= 2) { ra.chunk_samples = chunk; ra.n_chunks = pieces; }
+    }
     ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
@@ -762,11 +800,27 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     } else {
         // the counter keeps the last call's final value: it starts every call at zero
         if (!hip_ok(hipMemsetAsync(slot_counter, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
-        if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, st);
+        if (ra.n_chunks > 0) {
+            const size_t groups = ((size_t)ra.n_wave_tiles + 3) / 4;
+            const size_t states_bytes = ((size_t)p->nx * (size_t)p->ny * sizeof(unsigned long long) + 255) & ~(size_t)255;
+            const size_t words_bytes = (1 + groups) * sizeof(unsigned);
+            if (sc->chunk_workspace_bytes < states_bytes + words_bytes) {
+                if (sc->chunk_workspace) { (void)hipFree(sc->chunk_workspace); sc->chunk_workspace = nullptr; sc->chunk_workspace_bytes = 0; }
+                if (hipMalloc(&sc->chunk_workspace, states_bytes + words_bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sc->chunk_workspace = nullptr;
+                    pt::set_error("render: out of device memory for the chunked schedule's per-pixel state"); return PT_ERR_OOM;
+                }
+                sc->chunk_workspace_bytes = states_bytes + words_bytes;
+            }
+            unsigned* words = reinterpret_cast<unsigned*>(static_cast<char*>(sc->chunk_workspace) + states_bytes);
+            if (!hip_ok(hipMemsetAsync(words, 0, words_bytes, st), "hipMemsetAsync(chunk words)")) return PT_ERR_HIP;
+            launch_chunks(launch_variant(sc, ra), sc->view, ra, out, words, static_cast<unsigned long long*>(sc->chunk_workspace), sc->bad_resume_dev, st);
+        } else if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, st);
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
-        sc->last.schedule = ra.refill == 2 ? PT_SCHEDULE_WALK : ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
+        sc->last.schedule = ra.n_chunks > 0 ? PT_SCHEDULE_CHUNKS : ra.refill == 2 ? PT_SCHEDULE_WALK : ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
         sc->last.signature_walk = sc->variant == V_CORNELL_WORLD ? 1 : 0;
     }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
@@ -830,7 +884,12 @@ extern "C" int pt_frame_finish_device(void* d_frame, size_t n_floats, int32_t to
 static bool bad_resume(PtScene* sc)
 {
     if (!sc->bad_resume_host || !*(volatile int*)sc->bad_resume_host) return false;
+    const int what = *sc->bad_resume_host;
     *sc->bad_resume_host = 0;
+    if (what == 2) {
+        pt::set_error("render: PT_SCHEDULE_CHUNKS gave up waiting for a tile's previous chunk; the frame is not valid");
+        return true;
+    }
     pt::set_error("pt_render_pass: the accumulator does not hold the state of first_sample samples for every pixel of this shard "
                   "(resume from the array the earlier passes of this render wrote)");
     return true;
@@ -926,6 +985,7 @@ extern "C" int pt_render(PtScene* sc, const PtRenderParams* p, float* out_rgb)
     if (!d_out) return PT_ERR_OOM;
     int rc = pt_render_device(sc, p, d_out, nullptr);
     if (rc == PT_OK && !hip_ok(hipStreamSynchronize(nullptr), "render (synchronize)")) rc = PT_ERR_HIP;
+    if (rc == PT_OK && bad_resume(sc)) rc = PT_ERR_HIP;
     if (rc == PT_OK && !hip_ok(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy(frame)")) rc = PT_ERR_HIP;
     return rc;
 }

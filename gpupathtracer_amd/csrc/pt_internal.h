@@ -21,6 +21,7 @@ struct RenderArgs {
     int32_t walk_wait;             // shared walk: lanes with a finished search that make the wave leave the search loop
     int32_t raw_sum;               // write the plain sample sums instead of sqrt(sum / ns)
     uint64_t seed_offset;          // added to the pixel index before seeding (sample batches; 0 = the reference's stream)
+    int32_t chunk_samples, n_chunks;   // chunked tiles: samples per work item and items per tile (0: not chunked)
 };
 
 // Wave w of the launch -> its 8x8 pixel block.  Shard tiles owned by this shard are
@@ -80,6 +81,8 @@ struct PtScene {
     unsigned* next_slot = nullptr;      // device counter of the fused scheduler's pixel-slot pool
     int* bad_resume_host = nullptr;     // pinned host word a progressive pass raises when its accumulator is not at first_sample
     int* bad_resume_dev = nullptr;      // the same word as the device sees it
+    void* chunk_workspace = nullptr;    // chunked tiles: random-stream states (8 bytes per pixel), ticket and per-group progress words, kept between calls
+    size_t chunk_workspace_bytes = 0;
     void* wf_workspace = nullptr;       // staged scheduler: lane state and queues, kept between calls
     void* staging = nullptr;            // device side of the host-buffer entry points (pt_render, pt_trace_closest, ...), kept between calls
     size_t staging_bytes = 0;

@@ -198,6 +198,92 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
     lane_write_pixel(st, ra, i, out);
 }
 
+// k_render_tiles with every pixel's samples cut into chunks, for frames of few tiles and many samples: there
+// a wave tile is one long work item (1024^2 pixels at 4096 samples: 16 384 items of about 90 ms for 6 144 wave
+// slots), the launch ends with most of the GPU idle behind its last items, and the same paths traced as a
+// 4096^2 frame at 256 samples take 16 % less time.  Here the work item is (chunk, group of four wave tiles),
+// numbered chunk-major; persistent workgroups draw item numbers from a counter, so items start in order.
+// A pixel's samples stay one sequence (src/ptMain.cu:156-162): its random stream's state waits in `rng_states`
+// and its running sum in the frame itself between chunks, and chunk c of a group starts once the group's
+// progress word says chunk c - 1 has been stored.  That wait cannot deadlock: the item waited for has a
+// smaller number, so a running workgroup holds it, and the chain of waits ends at a chunk 0, which waits for
+// nothing.  The wait is bounded all the same; running out raises *fault (the frame is then wrong, and the
+// host says so).
+template <uint32_t F, class W>
+__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_chunks(SceneView sv, RenderArgs ra, float* __restrict__ out,
+                                                                             unsigned* __restrict__ words, unsigned long long* __restrict__ rng_states,
+                                                                             int* __restrict__ fault)
+{
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ float4 faces[FaceTable<F, W>::float4s];
+    __shared__ unsigned s_item;
+    face_table_to_lds<F, W>(sv, faces);
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
+    const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
+    const unsigned groups = (unsigned)(ra.n_wave_tiles + 3) / 4u;
+    const unsigned n_items = groups * (unsigned)ra.n_chunks;
+    unsigned* const progress = words + 1;
+    // Thread 0 has one errand per round, between the barrier that ends an item and the one that starts the next:
+    // publish the finished item, then draw the next number.  (Written as two -- one at the end of the loop body,
+    // one at its start -- the compiler joins them across the loop's back edge into a loop of thread 0's own and
+    // leaves the other lanes of its wave circling through the barriers without it.)
+    bool finished_one = false;
+    unsigned finished_grp = 0, finished_c = 0;
+    while (true) {
+        if (threadIdx.x == 0) {
+            if (finished_one) __hip_atomic_store(&progress[finished_grp], finished_c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = atomicAdd(&words[0], 1u);
+        }
+        __syncthreads();
+        // through a scalar register: the compiler must see that the whole workgroup leaves (or stays in) the loop
+        // together, or it arranges the loop for lanes that leave at different times and the barriers no longer pair up
+        const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (item >= n_items) break;
+        const int c = (int)(item / groups);
+        const unsigned grp = item - (unsigned)c * groups;
+        if (c > 0) {
+            if (threadIdx.x == 0) {
+                unsigned spins = 0;
+                // relaxed polls: an acquiring load invalidates the cache behind it every time, and a thousand waiting
+                // workgroups doing that made the working ones ten times slower; the fence below acquires once
+                while (__hip_atomic_load(&progress[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c) {
+                    __builtin_amdgcn_s_sleep(64);
+                    if (++spins > (1u << 23)) { *fault = 2; break; }
+                }
+            }
+            __syncthreads();
+            __threadfence();                                  // every wave: the loads below come after the word
+        }
+        const int wave = (int)grp * 4 + wave_in_block;
+        int x = 0, ytop = 0;
+        if (wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop)) {
+            LaneState st;
+            lane_init(st);
+            unsigned i;
+            lane_begin_pixel(st, ra, x, ytop, i);
+            if (c > 0) {
+                st.rng.state = rng_states[i];
+                st.accum = mk(out[3 * (size_t)i + 0], out[3 * (size_t)i + 1], out[3 * (size_t)i + 2]);
+                st.s = c * ra.chunk_samples;
+            }
+            RenderArgs part = ra;                             // this item's samples end where the next chunk begins
+            part.ns = min(ra.ns, (c + 1) * ra.chunk_samples);
+            while (!lane_step<F, W>(sv, part, st, fnx, fny, my_stack, faces)) {}
+            if (c == ra.n_chunks - 1) {
+                lane_write_pixel(st, ra, i, out);
+            } else {
+                rng_states[i] = st.rng.state;
+                out[3 * (size_t)i + 0] = st.accum.x; out[3 * (size_t)i + 1] = st.accum.y; out[3 * (size_t)i + 2] = st.accum.z;
+            }
+        }
+        __threadfence();                                      // every lane's stores before the word
+        __syncthreads();                                      // (also: everyone has read s_item)
+        finished_one = true; finished_grp = grp; finished_c = (unsigned)c;
+    }
+}
+
 // Fused scheduler with persistent lanes: a lane that has finished its pixel takes the next pixel
 // slot of the shard (slots are numbered tile by tile, 64 per 8x8 wave tile) from a device counter,
 // so a wave stays full until the shard runs out.  Pays when the closest-hit search, whose loop is
@@ -409,6 +495,13 @@ void FusedLaunch<F, W>::render(const SceneView& sv, const RenderArgs& ra, float*
         if constexpr ((F & F_LBVH) != 0) hipLaunchKernelGGL((k_render_walk<F>), grid, block, 0, st, sv, ra, out, next_slot);
     } else if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot);
     else hipLaunchKernelGGL((k_render_tiles<F, W>), grid, block, 0, st, sv, ra, out);
+}
+template <uint32_t F, class W>
+void FusedLaunch<F, W>::chunks(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault, hipStream_t st)
+{
+    const long long items = (long long)((ra.n_wave_tiles + 3) / 4) * ra.n_chunks;
+    const dim3 block(256), grid((unsigned)std::min<long long>(items, 2048));     // persistent: 256 CUs hold at most 6 each
+    hipLaunchKernelGGL((k_render_chunks<F, W>), grid, block, 0, st, sv, ra, out, words, rng_states, fault);
 }
 template <uint32_t F, class W>
 void FusedLaunch<F, W>::pass(const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume, hipStream_t st)

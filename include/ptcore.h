@@ -109,14 +109,21 @@ enum PtPipeline {
 /* How the fused scheduler hands pixels to lanes.  The image is the same either way. */
 enum PtSchedule {
     PT_SCHEDULE_AUTO   = 0, /* the measured best: WALK for triangles and for 64 or more spheres in the LBVH, TILES
-                             * for other worlds in the LBVH and for short lists, REFILL for reference BVHs walked as
+                             * for other worlds in the LBVH and for short lists (CHUNKS instead when the frame has
+                             * few tiles for the GPU and many samples), REFILL for reference BVHs walked as
                              * they are and for lists of more than 16 objects                                   */
     PT_SCHEDULE_TILES  = 1, /* one 8x8 tile per wave, one pixel per lane                                 */
     PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter                */
-    PT_SCHEDULE_WALK   = 3  /* REFILL, and the wave shares the closest-hit search one tree step at a time:
+    PT_SCHEDULE_WALK   = 3, /* REFILL, and the wave shares the closest-hit search one tree step at a time:
                              * lanes whose search has ended shade and start their next search while the
                              * others keep walking.  Worlds in the library's LBVH (PT_ACCEL_LBVH) with
                              * max_depth >= 1 only; PT_ERR_UNSUPPORTED otherwise.                          */
+    PT_SCHEDULE_CHUNKS = 4  /* TILES with every pixel's samples cut into chunks: (tile, chunk) pairs are handed to
+                             * workgroups in order from a device counter, a pixel's random stream and running sum
+                             * wait in device memory between its chunks (src/ptMain.cu:156-162 runs them as one
+                             * loop), so a frame of few tiles and many samples keeps the GPU full to its end.
+                             * PtRenderParams.chunk_samples sets the chunk.  Keeps 8 bytes per pixel of device
+                             * memory with the scene; PT_ERR_UNSUPPORTED from pt_render_device_noalloc.          */
 };
 
 /* Ids reported by pt_trace_closest. */
@@ -218,7 +225,8 @@ typedef struct PtRenderParams {
      * be added and finished once with pt_frame_finish_device.  Fused pipeline only. */
     int32_t batch_index, batch_count;
     int32_t raw_sum;
-    int32_t reserved[3];
+    int32_t chunk_samples; /* PT_SCHEDULE_CHUNKS: samples per chunk; 0 = the library's choice */
+    int32_t reserved[2];
 } PtRenderParams;
 
 /* One ray for pt_trace_closest.  The hit range is the integrator's [0.001, FLT_MAX]

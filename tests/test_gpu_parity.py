@@ -487,6 +487,63 @@ def test_wavefront_scheduler_large_frames_equal_the_fused_frame():
         assert_bit_exact(a, sc.render(nx, ny, ns), "%s %dx%d staged against fused" % (name, nx, ny))
 
 
+CHUNK_CASES = [("cornell", 1.0, {}), ("cornell_spheres", 1.0, {}), ("random", 2.0, {}), ("simple_light", 2.0, {}),
+               ("final", 16 / 9, {}), ("final", 16 / 9, dict(accel=abi.ACCEL_LBVH)), ("final", 16 / 9, dict(accel=abi.ACCEL_LBVH_BINARY)),
+               ("random", 2.0, dict(accel=abi.ACCEL_LBVH)), ("trimesh", 1.0, {})]
+
+
+@pytest.mark.parametrize("name,aspect,kw", CHUNK_CASES)
+def test_chunked_tiles_schedule_bit_exact(oracle, name, aspect, kw):
+    """PT_SCHEDULE_CHUNKS: a pixel's samples traced as several work items, its random stream and running sum
+    waiting in device memory in between.  Where the cuts fall never changes a sample: the oracle's frame for
+    every chunk size (one sample, sizes that do not divide the count, one chunk for everything), ragged
+    frames, shards that sum to the frame, raw sums of a sample batch, a bounce limit of zero, through a lens."""
+    d = pt.trimesh_scene(10, aspect) if name == "trimesh" else pt.builtin_scene(name, aspect, **kw)
+    sc = pt.Scene(d)
+    for nx, ny, ns, depth, chunk in ((96, 64, 12, 25, 5), (37, 23, 7, 25, 1), (64, 64, 9, 3, 4), (50, 50, 6, 0, 2), (80, 48, 8, 25, 8), (80, 48, 8, 25, 100)):
+        ref = oracle.render(d, nx, ny, ns, depth)
+        img = sc.render(nx, ny, ns, depth, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=chunk)
+        assert sc.stats().schedule == abi.SCHEDULE_CHUNKS
+        assert_bit_exact(img, ref, "%s %dx%d ns%d depth%d in chunks of %d" % (name, nx, ny, ns, depth, chunk))
+    assert_bit_exact(sc.render(96, 64, 12, schedule=abi.SCHEDULE_CHUNKS), oracle.render(d, 96, 64, 12), name + ", the library's chunk size")
+    full = sc.render(100, 60, 10, schedule=abi.SCHEDULE_TILES)
+    acc = np.zeros_like(full)
+    for s in range(3):
+        acc += sc.render(100, 60, 10, shard_index=s, shard_count=3, tile=(16, 8), schedule=abi.SCHEDULE_CHUNKS, chunk_samples=3)
+    assert_bit_exact(acc, full, name + " shards in chunks")
+    raw_tiles = sc.render(64, 40, 6, batch_index=1, batch_count=2, raw_sum=1, schedule=abi.SCHEDULE_TILES)
+    raw_chunks = sc.render(64, 40, 6, batch_index=1, batch_count=2, raw_sum=1, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=4)
+    assert_bit_exact(raw_chunks, raw_tiles, name + " raw sums of a sample batch in chunks")
+    with pytest.raises(pt.PtError):
+        sc.render(16, 16, 4, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=-1)
+
+
+def test_chunked_tiles_large_frames_and_the_lens():
+    """Frames with more work items than the GPU holds workgroups (so items wait for their tile's previous chunk
+    while others run), against the plain tile schedule's frame; what AUTO picks at the headline's size; the
+    entry point that may not allocate refuses the schedule."""
+    tex = np.random.default_rng(5).integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    for name, kw, nx, ny, ns, chunk in (("cornell", {}, 1021, 1003, 24, 2), ("cornell", {}, 517, 389, 64, 3),
+                                        ("final", dict(earth_rgb=tex, accel=abi.ACCEL_LBVH), 1021, 579, 6, 1),
+                                        ("cornell_spheres", {}, 640, 480, 12, 5)):
+        d = pt.builtin_scene(name, nx / ny, **kw)
+        if name == "cornell_spheres":
+            d.c.camera[23] = 4.0                                # a lens: more random numbers per sample
+        sc = pt.Scene(d)
+        ref = sc.render(nx, ny, ns, schedule=abi.SCHEDULE_TILES)
+        assert_bit_exact(sc.render(nx, ny, ns, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=chunk), ref, "%s %dx%d in chunks of %d" % (name, nx, ny, chunk))
+    sc = pt.Scene(pt.builtin_scene("cornell", 1.0))
+    ref = sc.render(1024, 1024, 128, schedule=abi.SCHEDULE_TILES)
+    img = sc.render(1024, 1024, 128)
+    assert sc.stats().schedule == abi.SCHEDULE_CHUNKS            # two rounds of tiles or more, 128 samples: cut in two
+    assert_bit_exact(img, ref, "the headline's frame size under AUTO")
+    sc.render(1024, 1024, 128, shard_index=0, shard_count=2)
+    assert sc.stats().schedule == abi.SCHEDULE_TILES             # a launch of less than two rounds is not cut
+    buf = pt.DeviceBuffer(64 * 64 * 12)
+    with pytest.raises(pt.PtError):
+        sc.render_device_noalloc(buf.ptr, 64, 64, 4, schedule=abi.SCHEDULE_CHUNKS)
+
+
 def test_cli_writes_every_image_format(tmp_path, oracle):
     """The C++ host (reference main()'s flags) renders through the C ABI and writes each format;
     8-bit pixels must be Clamp(int(255.99*c),0,255) of the oracle's frame."""
@@ -931,6 +988,8 @@ def test_random_rooms_match_the_oracle(oracle, seed):
     ref = oracle.render(g, 56, 56, 6, depth)
     for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
         assert_bit_exact(sc.render(56, 56, 6, depth, schedule=schedule), ref, "room %d schedule %d" % (seed, schedule))
+    chunk = int(rng.integers(1, 6))
+    assert_bit_exact(sc.render(56, 56, 6, depth, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=chunk), ref, "room %d in chunks of %d" % (seed, chunk))
     assert sc.stats().signature_walk == (0 if sky else 1)
     assert sc.stats().kernel_family == (abi.KERNELS_ALL if sky else abi.KERNELS_RECTANGLES)
     assert_bit_exact(sc.render(56, 56, 6, depth, pipeline=abi.PIPELINE_WAVEFRONT), ref, "room %d staged" % seed)
@@ -1493,6 +1552,7 @@ def test_random_worlds_of_the_final_scenes_kinds_match_the_oracle(oracle, seed):
             ref = oracle.render(g, 64, 32, 6)
         for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
             assert_bit_exact(sc.render(64, 32, 6, schedule=schedule), ref, "final-kind world %d accel %d schedule %d" % (seed, accel, schedule))
+        assert_bit_exact(sc.render(64, 32, 6, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=1 + seed % 4), ref, "final-kind world %d accel %d in chunks" % (seed, accel))
         assert_bit_exact(sc.render(64, 32, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, "final-kind world %d accel %d staged" % (seed, accel))
         assert sc.stats().kernel_family == abi.KERNELS_FINAL
 

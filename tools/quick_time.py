@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time of one scene at one size: python tools/quick_time.py cornell 1024 1024 256 [lbvh] [schedule N] [shards N] [wavefront]
+"""Kernel time of one scene at one size: python tools/quick_time.py cornell 1024 1024 256 [lbvh] [schedule N] [chunk SAMPLES] [shards N] [wavefront]
 Development tool."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,9 @@ accel = abi.ACCEL_LBVH if "lbvh" in rest else abi.ACCEL_LBVH_BINARY if "binary" 
 kw = {}
 if "schedule" in rest:
     kw["schedule"] = int(rest[rest.index("schedule") + 1])
+if "chunk" in rest:
+    kw["schedule"] = abi.SCHEDULE_CHUNKS
+    kw["chunk_samples"] = int(rest[rest.index("chunk") + 1])
 if "wavefront" in rest:
     kw["pipeline"] = abi.PIPELINE_WAVEFRONT
 if "shards" in rest:
