@@ -33,7 +33,7 @@ with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
     FLOP_PER_PATH = {k: v["flop_per_path"] for k, v in json.load(_f)["configs"].items()}
 # HBM bytes one launch moves, from the committed rocprofv3 PMC pass (FETCH_SIZE + WRITE_SIZE with
 # the guide's unit and gfx950 corrections): the frame is written once, the scene stays in cache.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_cornell1024x512_k_render_tiles.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_cornell1024x512_k_render_chunks.json")
 # fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).  Measured
 # (tools/valu_probe.hip): plain add/mul/fma on vector registers issue at that rate; compares, selects,
 # min/max, integer multiplies, fp64, conversions and the scale / fix-up steps of a divide at half of it.
@@ -207,7 +207,7 @@ def main():
                     traffic_note = "the committed PMC pass profiled another build of libptcore.so; not reported"
             roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_VALU_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                        "kernel": "k_render_refill" if fused_stats.schedule == 2 else "k_render_tiles",
+                        "kernel": {2: "k_render_refill", 3: "k_render_walk", 4: "k_render_chunks"}.get(fused_stats.schedule, "k_render_tiles"),
                         "kernel_ms": k_ms, "flop_per_path": flop, "paths_per_launch": shard_paths,
                         "peak_note": "fp32 VALU, one add/mul per lane per cycle, no FMA credit (parity forbids contraction); compares, "
                                      "selects, min/max, fp64 and divide scale/fix-up steps issue at half that rate (%.1f TFLOP/s)"

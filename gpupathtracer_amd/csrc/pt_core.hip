@@ -801,7 +801,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         // the counter keeps the last call's final value: it starts every call at zero
         if (!hip_ok(hipMemsetAsync(slot_counter, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
         if (ra.n_chunks > 0) {
-            const size_t groups = ((size_t)ra.n_wave_tiles + 3) / 4;
+            const size_t groups = (size_t)ra.n_wave_tiles;          // progress words: one per work item group, at most one per wave tile
             const size_t states_bytes = ((size_t)p->nx * (size_t)p->ny * sizeof(unsigned long long) + 255) & ~(size_t)255;
             const size_t words_bytes = (1 + groups) * sizeof(unsigned);
             if (sc->chunk_workspace_bytes < states_bytes + words_bytes) {

@@ -209,12 +209,18 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
 // smaller number, so a running workgroup holds it, and the chain of waits ends at a chunk 0, which waits for
 // nothing.  The wait is bounded all the same; running out raises *fault (the frame is then wrong, and the
 // host says so).
+#ifndef PT_CHUNK_WAVES
+#define PT_CHUNK_WAVES 4
+#endif
+// wave tiles per work item = waves per workgroup.  4 / 2 / 1 (-DPT_CHUNK_WAVES): rectangle scene 1024^2 x4096 213.2 / 216.5 / 211.8 ms,
+// RTNW final through the 4-wide tree 1920x1080 x256 192.0 / 190.9 / 187.0: the waves of a workgroup waiting for each other is not what is left
+constexpr int CHUNK_WAVES = PT_CHUNK_WAVES;
 template <uint32_t F, class W>
-__global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_chunks(SceneView sv, RenderArgs ra, float* __restrict__ out,
+__global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_render_chunks(SceneView sv, RenderArgs ra, float* __restrict__ out,
                                                                              unsigned* __restrict__ words, unsigned long long* __restrict__ rng_states,
                                                                              int* __restrict__ fault)
 {
-    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? CHUNK_WAVES * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[FaceTable<F, W>::float4s];
     __shared__ unsigned s_item;
     face_table_to_lds<F, W>(sv, faces);
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_chunks(Scen
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
     const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
-    const unsigned groups = (unsigned)(ra.n_wave_tiles + 3) / 4u;
+    const unsigned groups = (unsigned)(ra.n_wave_tiles + CHUNK_WAVES - 1) / (unsigned)CHUNK_WAVES;
     const unsigned n_items = groups * (unsigned)ra.n_chunks;
     unsigned* const progress = words + 1;
     // Thread 0 has one errand per round, between the barrier that ends an item and the one that starts the next:
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_chunks(Scen
             __syncthreads();
             __threadfence();                                  // every wave: the loads below come after the word
         }
-        const int wave = (int)grp * 4 + wave_in_block;
+        const int wave = (int)grp * CHUNK_WAVES + wave_in_block;
         int x = 0, ytop = 0;
         if (wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop)) {
             LaneState st;
@@ -499,8 +505,8 @@ void FusedLaunch<F, W>::render(const SceneView& sv, const RenderArgs& ra, float*
 template <uint32_t F, class W>
 void FusedLaunch<F, W>::chunks(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault, hipStream_t st)
 {
-    const long long items = (long long)((ra.n_wave_tiles + 3) / 4) * ra.n_chunks;
-    const dim3 block(256), grid((unsigned)std::min<long long>(items, 2048));     // persistent: 256 CUs hold at most 6 each
+    const long long items = (long long)((ra.n_wave_tiles + CHUNK_WAVES - 1) / CHUNK_WAVES) * ra.n_chunks;
+    const dim3 block(64 * CHUNK_WAVES), grid((unsigned)std::min<long long>(items, 8192 / CHUNK_WAVES));     // persistent: 256 CUs hold at most 24 waves each
     hipLaunchKernelGGL((k_render_chunks<F, W>), grid, block, 0, st, sv, ra, out, words, rng_states, fault);
 }
 template <uint32_t F, class W>

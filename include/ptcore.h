@@ -289,7 +289,9 @@ int  pt_render(PtScene* scene, const PtRenderParams* params, float* out_rgb);
  * hip_stream (a hipStream_t, NULL = default stream) without a host sync.  A scene renders one
  * frame at a time: its pixel-slot counter and timing events are per scene, so a call first makes
  * hip_stream wait for the scene's previous render (whatever stream that ran on).  To overlap
- * renders, create one scene per stream. */
+ * renders, create one scene per stream.  Two schedulers keep per-pixel state with the scene and
+ * allocate it in the first call of a frame size, which blocks while it does: PT_PIPELINE_WAVEFRONT
+ * for worlds searched through a tree, and PT_SCHEDULE_CHUNKS (which PT_SCHEDULE_AUTO may pick). */
 int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_rgb, void* hip_stream);
 
 /* pt_render_device for callers that cannot allocate device memory: code under HIP graph capture,
@@ -299,7 +301,8 @@ int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_
  * pixel-slot counter of the persistent-lane schedules (PT_SCHEDULE_REFILL / _WALK) -- lives in a
  * 256-byte array that is part of the library's device code, one copy per GPU, instead of in memory
  * the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its lane state:
- * PT_ERR_UNSUPPORTED); at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
+ * PT_ERR_UNSUPPORTED) and not PT_SCHEDULE_CHUNKS, which keeps per-pixel state in memory the scene
+ * allocates (PT_ERR_UNSUPPORTED when asked for; PT_SCHEDULE_AUTO never picks it here); at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
  * counter can number its pixel slots (PT_ERR_INVALID beyond); the scene's device must be current.
  * The counter is cleared at the start of every call.  All calls on one GPU share that GPU's
  * array, whatever the scene or stream: calls that overlap on one GPU race on it and trace pixels
