@@ -33,7 +33,7 @@ with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
     FLOP_PER_PATH = {k: v["flop_per_path"] for k, v in json.load(_f)["configs"].items()}
 # HBM bytes one launch moves, from the committed rocprofv3 PMC pass (FETCH_SIZE + WRITE_SIZE with
 # the guide's unit and gfx950 corrections): the frame is written once, the scene stays in cache.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_cornell1024x512_k_render_chunks.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_cornell1024x4096_k_render_chunks.json")
 # fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).  Measured
 # (tools/valu_probe.hip): plain add/mul/fma on vector registers issue at that rate; compares, selects,
 # min/max, integer multiplies, fp64, conversions and the scale / fix-up steps of a divide at half of it.
@@ -196,7 +196,7 @@ def main():
             # HBM bytes per launch come from a committed rocprofv3 PMC pass (counters cannot be read inside
             # this process); the file names the build it profiled, and a number from another build is not reported
             traffic, traffic_note = None, "no PMC pass for this workload"
-            if args.scene == "cornell" and nx == 1024 and ny == 1024 and world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
+            if args.scene == "cornell" and nx == 1024 and ny == 1024 and args.spp == 4096 and world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
                 with open(PMC_TRAFFIC_FILE) as f:
                     pmc = json.load(f)
                 if pmc.get("_libptcore_sha256") == library_sha256(pt.library_path()):

@@ -60,7 +60,7 @@ def main():
         print("oracle shard %d/%d, %.0f s" % (k + 1, a.shards, time.perf_counter() - t0), flush=True)
     cpu_s = time.perf_counter() - t0
     same = gpu.view(np.uint32) == cpu.view(np.uint32)
-    res = {"scene": ("trimesh %d" % a.trimesh) if a.trimesh else a.scene + (" + synthetic earth map" if a.earthmap else ""), "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "values": int(same.size), "values_different": int((~same).sum()),
+    res = {"scene": ("trimesh %d" % a.trimesh) if a.trimesh else a.scene + (" + synthetic earth map" if a.earthmap else ""), "nx": nx, "ny": ny, "spp": a.spp, "gpu_accel": "lbvh" if a.lbvh else "list", "gpu_pipeline": "wavefront" if a.wavefront else "fused", "gpu_schedule": sc.stats().schedule, "values": int(same.size), "values_different": int((~same).sum()),
            "oracle_seconds": cpu_s, "oracle_threads": a.threads, "oracle_Mpaths_per_s": nx * ny * a.spp / cpu_s / 1e6,
            "gpu_kernel_ms": sc.stats().kernel_ms, "frame_mean": float(gpu.mean())}
     print(json.dumps(res), flush=True)

@@ -10,9 +10,9 @@ T="timeout -k 10"
 stats_csv() { find "$1" -name '*kernel_stats.csv' | head -1; }
 
 echo "== counters of the headline kernel (bench.py quotes their HBM traffic while the stamp matches the library)"
-$T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_chunks -- python3 bench.py --steps 1 --warmup 0 --spp 512 --no-cpu-baseline --no-staged > $O/pmc_cornell.log
-cp $O/pmc_cornell/summary.json $O/pmc_cornell1024x512_k_render_chunks.json
-mkdir -p profiles/$R && cp $O/pmc_cornell1024x512_k_render_chunks.json profiles/$R/
+$T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_chunks -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-staged > $O/pmc_cornell.log
+cp $O/pmc_cornell/summary.json $O/pmc_cornell1024x4096_k_render_chunks.json
+mkdir -p profiles/$R && cp $O/pmc_cornell1024x4096_k_render_chunks.json profiles/$R/
 echo "== bench.py default"
 $T 600 python3 bench.py > $O/bench_cornell1024x4096_default.json
 cat $O/bench_cornell1024x4096_default.json
