@@ -533,6 +533,9 @@ def test_chunked_tiles_large_frames_and_the_lens():
         ref = sc.render(nx, ny, ns, schedule=abi.SCHEDULE_TILES)
         assert_bit_exact(sc.render(nx, ny, ns, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=chunk), ref, "%s %dx%d in chunks of %d" % (name, nx, ny, chunk))
     sc = pt.Scene(pt.builtin_scene("cornell", 1.0))
+    # one tile, 600 work items in a chain: every workgroup but one waits for its predecessor
+    assert_bit_exact(sc.render(8, 8, 600, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=1), sc.render(8, 8, 600, schedule=abi.SCHEDULE_TILES), "one tile in 600 chunks")
+    assert_bit_exact(sc.render(40, 24, 96, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=1), sc.render(40, 24, 96, schedule=abi.SCHEDULE_TILES), "fifteen tiles in 96 chunks each")
     ref = sc.render(1024, 1024, 128, schedule=abi.SCHEDULE_TILES)
     img = sc.render(1024, 1024, 128)
     assert sc.stats().schedule == abi.SCHEDULE_CHUNKS            # two rounds of tiles or more, 128 samples: cut in two
