@@ -773,18 +773,40 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         }
         chunk = std::max(1, std::min(chunk, std::max(1, p->ns)));
         const int pieces = std::max(1, (p->ns + chunk - 1) / chunk);
+        // work items (chunk, group of wave tiles) are numbered, and drawn from a counter, in 32 bits
+        if ((long long)ra.n_wave_tiles * pieces > 0x7fffffffLL) {
+            pt::set_error("render: PT_SCHEDULE_CHUNKS with this chunk_samples cuts the shard into more than 2^31 work items; use larger chunks");
+            return PT_ERR_INVALID;
+        }
         if (p->schedule == PT_SCHEDULE_CHUNKS || pieces >= 2) { ra.chunk_samples = chunk; ra.n_chunks = pieces; }
     }
     ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
+    // A stream under graph capture records the work, it does not run it: the scene's timing events stay out of the
+    // graph (an event recorded there belongs to the capture and can no longer be waited for or timed from outside
+    // it), so pt_render_stats keeps describing the last render that ran outside a graph; replays are ordered by the
+    // stream they are launched on.
+    bool capturing = false;
+    if (st) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (!hip_ok(hipStreamIsCapturing(st, &cs), "hipStreamIsCapturing")) return PT_ERR_HIP;
+        capturing = cs != hipStreamCaptureStatusNone;
+    }
+    if (capturing && ra.n_chunks > 0 && p->schedule == PT_SCHEDULE_AUTO) ra.n_chunks = ra.chunk_samples = 0;     // AUTO: one tile per wave instead
+    if (capturing && (p->pipeline == PT_PIPELINE_WAVEFRONT || ra.n_chunks > 0)) {
+        pt::set_error("render: a stream under graph capture takes the fused pipeline's TILES, REFILL and WALK schedules only "
+                      "(the staged pipeline synchronises with the host, the CHUNKS schedule may allocate)");
+        return PT_ERR_UNSUPPORTED;
+    }
     // One render of a scene at a time: the pixel-slot counter and the timing events belong to the
     // scene, so a call on another stream first waits for the scene's previous render to finish.
-    if (sc->have_timing && !hip_ok(hipStreamWaitEvent(st, sc->ev_end, 0), "hipStreamWaitEvent")) return PT_ERR_HIP;
-    if (!hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
+    if (!capturing && sc->have_timing && !hip_ok(hipStreamWaitEvent(st, sc->ev_end, 0), "hipStreamWaitEvent")) return PT_ERR_HIP;
+    if (!capturing && !hip_ok(hipEventRecord(sc->ev_begin, st), "hipEventRecord")) return PT_ERR_HIP;
     // pixels this shard does not own must read as zero so that shards sum to the frame
     if (!hip_ok(hipMemsetAsync(out, 0, (size_t)3 * p->nx * p->ny * sizeof(float), st), "hipMemsetAsync")) return PT_ERR_HIP;
-    if (!hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
+    if (!capturing && !hip_ok(hipEventRecord(sc->ev_k0, st), "hipEventRecord")) return PT_ERR_HIP;
+    const PtRenderStats before_capture = sc->last;
     sc->last = PtRenderStats{};
     sc->last.kernel_family = kernel_family(sc->variant);
     if (p->pipeline == PT_PIPELINE_WAVEFRONT && (ra.seed_offset != 0 || ra.raw_sum)) {
@@ -823,6 +845,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         sc->last.schedule = ra.n_chunks > 0 ? PT_SCHEDULE_CHUNKS : ra.refill == 2 ? PT_SCHEDULE_WALK : ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
         sc->last.signature_walk = sc->variant == V_CORNELL_WORLD ? 1 : 0;
     }
+    if (capturing) { sc->last = before_capture; return PT_OK; }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;
     if (!hip_ok(hipEventRecord(sc->ev_end, st), "hipEventRecord")) return PT_ERR_HIP;
     sc->have_timing = true;
@@ -1021,6 +1044,7 @@ extern "C" int pt_render_on_devices(const PtSceneDesc* desc, const PtRenderParam
     for (int g = 0; g < n_devices && rc == PT_OK; g++) {
         if (!hip_ok(hipSetDevice(device_ids[g]), "hipSetDevice") || !hip_ok(hipDeviceSynchronize(), "render (synchronize)") ||
             !hip_ok(hipMemcpy(part.data(), frames[(size_t)g], n_floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(frame)")) { rc = PT_ERR_HIP; break; }
+        if (bad_resume(scenes[(size_t)g])) { rc = PT_ERR_HIP; break; }     // a chunked launch that gave up waiting: the shard is not valid
         for (size_t i = 0; i < n_floats; i++) out_rgb[i] += part[i];      // shards are disjoint and zero elsewhere: x + 0 = x
     }
     for (int g = 0; g < n_devices; g++) {

@@ -251,10 +251,16 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
         const unsigned grp = item - (unsigned)c * groups;
         if (c > 0) {
             if (threadIdx.x == 0) {
-                unsigned spins = 0;
+                // The bound is on time without progress, not on time: the group's word counts the chunks stored so far, and
+                // a long chain of waits (few groups, long chunks) moves it while this workgroup waits.  Only a word that
+                // stands still for 2^23 polls (about 14 s) is given up on.
+                unsigned spins = 0, seen = 0;
                 // relaxed polls: an acquiring load invalidates the cache behind it every time, and a thousand waiting
                 // workgroups doing that made the working ones ten times slower; the fence below acquires once
-                while (__hip_atomic_load(&progress[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c) {
+                while (true) {
+                    const unsigned now = __hip_atomic_load(&progress[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (now >= (unsigned)c) break;
+                    if (now != seen) { seen = now; spins = 0; }
                     __builtin_amdgcn_s_sleep(64);
                     if (++spins > (1u << 23)) { *fault = 2; break; }
                 }

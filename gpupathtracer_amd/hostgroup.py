@@ -47,21 +47,48 @@ def _start_ticks(pid):
         return "0"
 
 
-class FileGroup:
-    """Rendezvous of `world` ranks through a directory on the local file system."""
+def launch_key():
+    """What tells one launch's ranks from another's on this node.  A launcher that names its run
+    (PT_RENDEZVOUS_ID, or torch.distributed.run's TORCHELASTIC_RUN_ID when it is not the default "none")
+    is taken at its word: the ranks then need not share a parent process.  Otherwise the ranks of one
+    launch share the launcher as parent; the parent's start time (clock ticks since boot) keeps a
+    directory a crashed launch left behind from being taken for this one's when process ids come round."""
+    named = os.environ.get("PT_RENDEZVOUS_ID") or os.environ.get("TORCHELASTIC_RUN_ID")
+    if named and named != "none":
+        return "id_" + "".join(c if c.isalnum() or c in "-_." else "_" for c in named)[:64]
+    return "ppid_%d_%s" % (os.getppid(), _start_ticks(os.getppid()))
 
-    def __init__(self, rank, world, directory=None, timeout=300.0):
+
+class FileGroup:
+    """Rendezvous of `world` ranks through a directory on the local file system.
+
+    The directory is private to the user (mode 0700, ownership checked: ranks read RCCL's id and, in the
+    rehearsal path, frame bytes from it).  `timeout` bounds every wait; the default (PT_RENDEZVOUS_TIMEOUT,
+    60 s) is sized for ranks that start seconds apart on a cold machine, and the error names the directory
+    so that a launcher whose ranks do not agree on it is found at once."""
+
+    def __init__(self, rank, world, directory=None, timeout=None):
+        if timeout is None:
+            timeout = float(os.environ.get("PT_RENDEZVOUS_TIMEOUT", "60"))
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        self.key = launch_key()
         if directory is None:
-            # the ranks of one launch share the launcher as parent and the port it was given; the parent's start
-            # time (clock ticks since boot) keeps a directory a crashed launch left behind from being taken for
-            # this one's when process ids come round again
-            directory = os.path.join(os.environ.get("PT_RENDEZVOUS_ROOT", "/tmp"),
-                                     "ptgroup_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), _start_ticks(os.getppid())))
+            root = os.environ.get("PT_RENDEZVOUS_ROOT")
+            if not root:
+                xdg = os.environ.get("XDG_RUNTIME_DIR")           # the user's own run-time directory where there is one
+                root = xdg if xdg and os.path.isdir(xdg) and os.access(xdg, os.W_OK | os.X_OK) else "/tmp"
+            directory = os.path.join(root, "ptgroup_%d_%s_%s" % (os.geteuid(), os.environ.get("MASTER_PORT", "0"), self.key))
         self.dir = directory
-        os.makedirs(self.dir, exist_ok=True)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        st = os.stat(self.dir)
+        if st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+            raise PermissionError("rank %d: rendezvous directory %s belongs to uid %d with mode %o; it must be this user's and private "
+                                  "(set PT_RENDEZVOUS_ROOT to a directory of your own)" % (self.rank, self.dir, st.st_uid, st.st_mode & 0o777))
         self._seq = 0
         self._last_file = None
+        # Files older than this are another launch's leftovers (a crashed run under a launch name that was
+        # used again): they are waited past, not read.  Ranks of one launch start seconds apart.
+        self._not_before = time.time() - 600.0
 
     # ---- small files, written atomically -------------------------------------------------------
     def _path(self, name):
@@ -80,10 +107,14 @@ class FileGroup:
         while True:
             try:
                 with open(path, "rb") as f:
-                    return f.read()
+                    if os.fstat(f.fileno()).st_mtime >= self._not_before:
+                        return f.read()
+                raise FileNotFoundError(path)                     # stale: wait for this launch's file to replace it
             except FileNotFoundError:
                 if time.monotonic() > deadline:
-                    raise TimeoutError("rank %d: %s did not appear within %.0f s" % (self.rank, path, self.timeout))
+                    raise TimeoutError("rank %d of %d: %s did not appear within %.0f s.  Every rank of a launch must compute the same "
+                                       "rendezvous directory (%s, keyed %s): start the ranks from one parent process, or export the same "
+                                       "PT_RENDEZVOUS_ID (and MASTER_PORT) to all of them" % (self.rank, self.world, path, self.timeout, self.dir, self.key))
                 time.sleep(delay)
                 delay = min(delay * 1.5, 0.01)
 

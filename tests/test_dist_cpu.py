@@ -119,3 +119,53 @@ def test_mapped_runtime_report_names_one_hip_runtime():
     (hip, rccl), torch_loaded = __import__("json").loads(out.strip().splitlines()[-1])
     assert len(hip) == 1 and len(rccl) == 1 and not torch_loaded
     assert "/torch/" not in hip[0] and "/torch/" not in rccl[0]
+
+
+def test_ranks_named_by_the_launcher_need_no_common_parent(monkeypatch, tmp_path):
+    """A launcher that gives its ranks different parents names the launch instead (PT_RENDEZVOUS_ID, or a
+    TORCHELASTIC_RUN_ID other than the default "none"): the directory then does not depend on the parent."""
+    from gpupathtracer_amd import hostgroup
+    monkeypatch.setenv("PT_RENDEZVOUS_ROOT", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29517")
+    monkeypatch.delenv("PT_RENDEZVOUS_ID", raising=False)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    by_parent = hostgroup.FileGroup(0, 2).dir
+    assert ("ppid_%d_" % os.getppid()) in by_parent
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job 42/a")
+    by_run = hostgroup.FileGroup(0, 2).dir
+    assert by_run.endswith("id_job_42_a") and str(os.getppid()) not in os.path.basename(by_run).split("id_")[1]
+    monkeypatch.setenv("PT_RENDEZVOUS_ID", "mine")                       # the library's own variable wins
+    assert hostgroup.FileGroup(1, 2).dir.endswith("29517_id_mine")
+    assert oct(os.stat(by_run).st_mode & 0o777) == oct(0o700)
+
+
+def test_a_rank_left_alone_fails_soon_and_names_the_directory(monkeypatch, tmp_path):
+    from gpupathtracer_amd import hostgroup
+    monkeypatch.setenv("PT_RENDEZVOUS_ROOT", str(tmp_path))
+    monkeypatch.setenv("PT_RENDEZVOUS_TIMEOUT", "0.3")
+    g = hostgroup.FileGroup(1, 2)
+    with pytest.raises(TimeoutError) as e:
+        g.broadcast("rccl_unique_id")
+    assert g.dir in str(e.value) and "PT_RENDEZVOUS_ID" in str(e.value)
+
+
+def test_a_rendezvous_directory_others_can_write_is_refused(tmp_path):
+    from gpupathtracer_amd import hostgroup
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    with pytest.raises(PermissionError):
+        hostgroup.FileGroup(0, 2, directory=str(loose))
+
+
+def test_a_file_left_by_an_old_launch_is_waited_past(tmp_path):
+    from gpupathtracer_amd import hostgroup
+    d = tmp_path / "g"
+    g = hostgroup.FileGroup(1, 2, directory=str(d), timeout=0.3)
+    stale = d / "rccl_unique_id"
+    stale.write_bytes(b"old")
+    os.utime(stale, (1.0e9, 1.0e9))
+    with pytest.raises(TimeoutError):
+        g.broadcast("rccl_unique_id")
+    hostgroup.FileGroup(0, 2, directory=str(d)).broadcast("rccl_unique_id", b"new")
+    assert g.broadcast("rccl_unique_id") == b"new"

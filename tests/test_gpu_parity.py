@@ -225,6 +225,58 @@ def test_full_size_frame_properties(oracle):
     assert st.paths == 1024 * 1024 * 16 // 8 and st.kernel_ms > 0
 
 
+def _earth_map_512x256():
+    """The arithmetic 512x256 RGB8 pattern the benchmarks use in place of the reference's earthmap.jpg."""
+    j, i = np.mgrid[0:256, 0:512]
+    return np.stack([(i * 7 + j * 13) & 255, (i ^ (j * 3)) & 255, ((i * j) >> 3) & 255], -1).astype(np.uint8)
+
+
+def test_rtiow_at_its_benchmark_size(oracle):
+    """BASELINE configs[1] at its own frame size: random_scene 1920x1080 through the library's tree under
+    the shared walk.  The oracle walks the flat list (about 1 Mpaths/s), so it checks 1 spp; beyond that
+    the properties that do not depend on size: determinism, eight tile shards summing to the frame, the
+    staged pipeline's frame equal to the fused one."""
+    d = pt.builtin_scene("random", 16 / 9, accel=abi.ACCEL_LBVH)
+    sc = pt.Scene(d)
+    assert sc.lbvh_form() == 4
+    img = sc.render(1920, 1080, 1)
+    assert sc.stats().schedule == abi.SCHEDULE_WALK             # what AUTO picks for this world
+    assert_bit_exact(img, oracle.render(d, 1920, 1080, 1, threads=16), "random_scene 1920x1080 x1")
+    a = sc.render(1920, 1080, 8)
+    assert_bit_exact(sc.render(1920, 1080, 8), a, "determinism")
+    assert_bit_exact(sc.render(1920, 1080, 8, schedule=abi.SCHEDULE_TILES), a, "one tile per wave")
+    assert_bit_exact(sc.render(1920, 1080, 8, pipeline=abi.PIPELINE_WAVEFRONT), a, "staged pipeline")
+    acc = np.zeros_like(a)
+    for s in range(8):
+        acc += sc.render(1920, 1080, 8, shard_index=s, shard_count=8)
+    assert_bit_exact(acc, a, "8 shards")
+    assert sc.stats().paths == (1920 // 8) * (1080 // 8) * 64 * 8 // 8
+
+
+def test_final_scene_at_its_benchmark_size(oracle):
+    """BASELINE configs[3] at its own frame size: the RTNW final scene with a 512x256 earth map, all ten
+    world objects, the reference BVH's boxes in the library's tree, 1920x1080.  The oracle checks 2 spp
+    through the tree and through the reference's own BVH; then chunks of samples against one launch per
+    tile, the staged pipeline against the fused one, eight shards against the frame."""
+    tex = _earth_map_512x256()
+    d = pt.builtin_scene("final", 16 / 9, earth_rgb=tex, accel=abi.ACCEL_LBVH)
+    assert d.c.n_world == 10
+    sc = pt.Scene(d)
+    assert sc.lbvh_form() == 4
+    ref = oracle.render(d, 1920, 1080, 2, threads=16)
+    assert_bit_exact(sc.render(1920, 1080, 2), ref, "final 1920x1080 x2 through the tree")
+    assert_bit_exact(pt.Scene(pt.builtin_scene("final", 16 / 9, earth_rgb=tex)).render(1920, 1080, 2), ref,
+                     "final 1920x1080 x2 through the reference's BVH")
+    a = sc.render(1920, 1080, 8, schedule=abi.SCHEDULE_TILES)
+    assert_bit_exact(sc.render(1920, 1080, 8, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=3), a, "chunks of 3 samples")
+    assert sc.stats().schedule == abi.SCHEDULE_CHUNKS
+    assert_bit_exact(sc.render(1920, 1080, 8, pipeline=abi.PIPELINE_WAVEFRONT), a, "staged pipeline")
+    acc = np.zeros_like(a)
+    for s in range(8):
+        acc += sc.render(1920, 1080, 8, shard_index=s, shard_count=8)
+    assert_bit_exact(acc, a, "8 shards")
+
+
 def test_device_libm_matches_glibc(oracle):
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-130, 130, 1_000_000), rng.uniform(-7, 7, 1_000_000),
@@ -311,6 +363,10 @@ def test_bad_render_arguments_are_errors():
     with pytest.raises(pt.PtError) as e:
         sc.render_device(small.ptr, 8192, 8192, 1, tile=(1, 1))
     assert e.value.code == abi.ERR_INVALID and "tiles" in str(e.value)
+    # chunks of one sample on a frame of 2^20 wave tiles at 4096 samples: 2^32 work items for a 32-bit ticket counter
+    with pytest.raises(pt.PtError) as e:
+        sc.render_device(small.ptr, 8192, 8192, 4096, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=1)
+    assert e.value.code == abi.ERR_INVALID and "work items" in str(e.value)
 
 
 @pytest.mark.parametrize("name,aspect,nx,ny,ns", SCENES)

@@ -75,3 +75,51 @@ def test_noalloc_render_limits_are_errors():
     sc.render_device_noalloc(frame.ptr, 64, 64, 1)                    # still usable
     pt.synchronize()
     assert np.isfinite(frame.to_host()).all()
+
+
+def _hip_runtime():
+    """The HIP runtime libptcore.so itself is linked against (already mapped: no second runtime is loaded)."""
+    import ctypes
+    from gpupathtracer_amd.hostgroup import mapped_runtimes
+    pt.library()
+    hip, _ = mapped_runtimes()
+    assert len(hip) == 1
+    return ctypes.CDLL(hip[0])
+
+
+def test_noalloc_render_captured_into_a_graph_and_replayed():
+    """What the entry point is for: a render recorded under HIP graph capture (no allocation may happen
+    there), replayed twice, the second time after the frame was overwritten; then the scene renders and
+    reports statistics normally again.  The library keeps its timing events out of the captured stream."""
+    import ctypes as C
+    hip = _hip_runtime()
+    sc = pt.Scene(pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH))
+    nx, ny, ns = 160, 80, 3
+    frame = pt.DeviceBuffer(nx * ny * 12)
+    sc.render_device(frame.ptr, nx, ny, ns)
+    pt.synchronize()
+    want = frame.to_host().copy()
+    stats_before = sc.stats()
+    stream, graph, exe = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    assert hip.hipStreamBeginCapture(stream, 0) == 0                  # hipStreamCaptureModeGlobal
+    try:
+        sc.render_device_noalloc(frame.ptr, nx, ny, ns, stream=stream.value)
+        with pytest.raises(pt.PtError):                               # the staged pipeline cannot be recorded
+            sc.render_device(frame.ptr, nx, ny, ns, stream=stream.value, pipeline=abi.PIPELINE_WAVEFRONT)
+    finally:
+        assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0
+    hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    assert hip.hipGraphInstantiate(C.byref(exe), graph, None, None, 0) == 0
+    for _ in range(2):
+        frame.from_host(np.full(nx * ny * 3, 7.0, np.float32))
+        assert hip.hipGraphLaunch(exe, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert np.array_equal(bits(frame.to_host()), bits(want))
+    assert sc.stats().kernel_ms == stats_before.kernel_ms             # still the render that ran outside the graph
+    frame.from_host(np.full(nx * ny * 3, 7.0, np.float32))
+    sc.render_device_noalloc(frame.ptr, nx, ny, ns)                   # the scene's own events were never captured
+    pt.synchronize()
+    assert np.array_equal(bits(frame.to_host()), bits(want))
+    assert sc.stats().paths == nx * ny * ns
+    assert hip.hipGraphExecDestroy(exe) == 0 and hip.hipGraphDestroy(graph) == 0 and hip.hipStreamDestroy(stream) == 0
