@@ -95,7 +95,7 @@ class PtRay(C.Structure):
 class PtRenderStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("n_launches", C.c_int32),
                 ("pipeline", C.c_int32), ("paths", C.c_uint64), ("schedule", C.c_int32), ("signature_walk", C.c_int32),
-                ("kernel_family", C.c_int32), ("reserved0", C.c_int32), ("reserved", C.c_uint64 * 2)]
+                ("kernel_family", C.c_int32), ("n_chunks", C.c_int32), ("reserved", C.c_uint64 * 2)]
 
 
 assert C.sizeof(PtShape) == 64

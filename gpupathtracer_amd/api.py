@@ -295,6 +295,7 @@ class RenderStats:
         self.schedule = int(s.schedule)
         self.signature_walk = int(s.signature_walk)
         self.kernel_family = int(s.kernel_family)
+        self.n_chunks = int(s.n_chunks)
 
 
 def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0,

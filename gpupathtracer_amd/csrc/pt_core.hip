@@ -76,9 +76,10 @@ int pick_variant(uint32_t scene_mask)
     default: LAUNCH(M_ALL_LBVH4, AnyWorld); break;                     \
     }
 
-void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
+void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, unsigned long long* chunk_rec, int* fault,
+                   hipStream_t st)
 {
-#define PT_LAUNCH(F, W) FusedLaunch<F, W>::render(sv, ra, out, next_slot, st)
+#define PT_LAUNCH(F, W) FusedLaunch<F, W>::render(sv, ra, out, next_slot, chunk_rec, fault, st)
     PT_FOR_VARIANT(variant, PT_LAUNCH)
 #undef PT_LAUNCH
 }
@@ -780,6 +781,34 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         }
         if (p->schedule == PT_SCHEDULE_CHUNKS || pieces >= 2) { ra.chunk_samples = chunk; ra.n_chunks = pieces; }
     }
+    // The persistent-lane schedules (REFILL, WALK) in chunks of a pixel's samples: slots are (chunk, pixel), see
+    // chunk_record_store.  With more pixels than lanes an uncut launch ends pixel by pixel (the lanes that drew the last
+    // slots trace whole pixels while the rest of the GPU has run dry); in chunks every pixel advances sweep by sweep and
+    // the launch ends within a chunk.  What a cut costs is the wave, not the lane: the lane's new slot (an atomic's round
+    // trip), its pixel's record (another) and the code around them run for one lane while 63 wait.  Measured (MI355X,
+    // kernel ms, uncut / 4 / 8 / 16 / 32 chunks): random spheres in the tree under WALK 1920x1080 x256 139.8 / 136.4 /
+    // 152.1 / 203.7 / 272.0 (the same paths as a 3840x2160 frame at 64 samples, where the end does not matter, take 124.5:
+    // the cuts' price is what keeps the rest of that gain); 2 M triangles under WALK 3840x2160 x64 157.1 / 192.7 / 225.5 (a
+    // wave waiting on memory all along pays most for one more wait); RTNW final through the reference's tree under REFILL
+    // x64 163.0 / 158.7 / 158.0, x256 639.4 / - / - / 626.6; random spheres over the flat list under REFILL x16 90.4 / 77.4
+    // (a list walk is uniform over the wave and long: the cut is cheap beside it).  So: REFILL up to 8 chunks of at least 4
+    // samples, WALK 4 chunks of at least 32 samples and none with triangles, only for shards of more than one and a half
+    // sweeps of the GPU's lanes.  chunk_samples: 0 the library's choice, >= ns no chunks.
+    if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill != 0 && ra.n_wave_tiles > 0 && !no_alloc && p->ns >= 2) {
+        const long long lanes = 256LL * 4 * 64 * 6, slots = (long long)ra.n_wave_tiles * 64;
+        int pieces = 1;
+        if (p->chunk_samples > 0) pieces = (p->ns + p->chunk_samples - 1) / p->chunk_samples;
+        else if (2 * slots > 3 * lanes) {
+            if (ra.refill == 1) pieces = std::min(8, p->ns / 4);
+            else if (!(sc->mask & ptd::F_TRIANGLE)) pieces = std::min(4, p->ns / 32);
+        }
+        pieces = (int)std::min<long long>(pieces, 0xffffffffLL / slots);      // slots are numbered in 32 bits
+        if (pieces >= 2) {
+            ra.chunk_samples = (p->ns + pieces - 1) / pieces;
+            ra.n_chunks = (p->ns + ra.chunk_samples - 1) / ra.chunk_samples;
+            if (ra.n_chunks < 2) ra.chunk_samples = ra.n_chunks = 0;
+        }
+    }
     ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
@@ -793,7 +822,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         if (!hip_ok(hipStreamIsCapturing(st, &cs), "hipStreamIsCapturing")) return PT_ERR_HIP;
         capturing = cs != hipStreamCaptureStatusNone;
     }
-    if (capturing && ra.n_chunks > 0 && p->schedule == PT_SCHEDULE_AUTO) ra.n_chunks = ra.chunk_samples = 0;     // AUTO: one tile per wave instead
+    if (capturing && ra.n_chunks > 0 && (p->schedule == PT_SCHEDULE_AUTO || ra.refill != 0)) ra.n_chunks = ra.chunk_samples = 0;     // one work item per pixel or tile instead
     if (capturing && (p->pipeline == PT_PIPELINE_WAVEFRONT || ra.n_chunks > 0)) {
         pt::set_error("render: a stream under graph capture takes the fused pipeline's TILES, REFILL and WALK schedules only "
                       "(the staged pipeline synchronises with the host, the CHUNKS schedule may allocate)");
@@ -822,7 +851,20 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     } else {
         // the counter keeps the last call's final value: it starts every call at zero
         if (!hip_ok(hipMemsetAsync(slot_counter, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
-        if (ra.n_chunks > 0) {
+        if (ra.n_chunks > 0 && ra.refill != 0) {
+            const size_t rec_bytes = (size_t)p->nx * (size_t)p->ny * 5 * sizeof(unsigned long long);     // CHUNK_REC_WORDS per pixel
+            if (sc->chunk_workspace_bytes < rec_bytes) {
+                if (sc->chunk_workspace) { (void)hipFree(sc->chunk_workspace); sc->chunk_workspace = nullptr; sc->chunk_workspace_bytes = 0; }
+                if (hipMalloc(&sc->chunk_workspace, rec_bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sc->chunk_workspace = nullptr;
+                    if (p->chunk_samples > 0) { pt::set_error("render: out of device memory for the chunk records of the persistent-lane schedule"); return PT_ERR_OOM; }
+                    ra.chunk_samples = ra.n_chunks = 0;             // the library's own choice: trace the pixels whole instead
+                } else sc->chunk_workspace_bytes = rec_bytes;
+            }
+            if (ra.n_chunks > 0 && !hip_ok(hipMemsetAsync(sc->chunk_workspace, 0, rec_bytes, st), "hipMemsetAsync(chunk records)")) return PT_ERR_HIP;
+            launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, static_cast<unsigned long long*>(sc->chunk_workspace), sc->bad_resume_dev, st);
+        } else if (ra.n_chunks > 0) {
             const size_t groups = (size_t)ra.n_wave_tiles;          // progress words: one per work item group, at most one per wave tile
             const size_t states_bytes = ((size_t)p->nx * (size_t)p->ny * sizeof(unsigned long long) + 255) & ~(size_t)255;
             const size_t words_bytes = (1 + groups) * sizeof(unsigned);
@@ -838,12 +880,13 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
             unsigned* words = reinterpret_cast<unsigned*>(static_cast<char*>(sc->chunk_workspace) + states_bytes);
             if (!hip_ok(hipMemsetAsync(words, 0, words_bytes, st), "hipMemsetAsync(chunk words)")) return PT_ERR_HIP;
             launch_chunks(launch_variant(sc, ra), sc->view, ra, out, words, static_cast<unsigned long long*>(sc->chunk_workspace), sc->bad_resume_dev, st);
-        } else if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, st);
+        } else if (ra.n_wave_tiles > 0) launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, nullptr, sc->bad_resume_dev, st);
         if (!hip_ok(hipGetLastError(), "render kernel launch")) return PT_ERR_HIP;
         sc->last.n_launches = ra.n_wave_tiles > 0 ? 1 : 0;
         sc->last.pipeline = PT_PIPELINE_FUSED;
-        sc->last.schedule = ra.n_chunks > 0 ? PT_SCHEDULE_CHUNKS : ra.refill == 2 ? PT_SCHEDULE_WALK : ra.refill ? PT_SCHEDULE_REFILL : PT_SCHEDULE_TILES;
+        sc->last.schedule = ra.refill == 2 ? PT_SCHEDULE_WALK : ra.refill ? PT_SCHEDULE_REFILL : ra.n_chunks > 0 ? PT_SCHEDULE_CHUNKS : PT_SCHEDULE_TILES;
         sc->last.signature_walk = sc->variant == V_CORNELL_WORLD ? 1 : 0;
+        sc->last.n_chunks = ra.n_chunks;
     }
     if (capturing) { sc->last = before_capture; return PT_OK; }
     if (!hip_ok(hipEventRecord(sc->ev_k1, st), "hipEventRecord")) return PT_ERR_HIP;

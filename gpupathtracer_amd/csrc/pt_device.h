@@ -51,6 +51,30 @@ enum : uint32_t {
 
 constexpr float PI_F = 3.141592654f;   // CUDART_PI_F
 
+// Section timers of a kernel experiment (-DPT_PROFILE on one translation unit, tools/section_profile.py): every wave
+// adds up, per section of its loop, the clock ticks spent, the lanes that had work there and the times it ran, and
+// adds its sums to a device array when it ends.  Without the flag the type is empty and the calls vanish.
+#ifdef PT_PROFILE
+constexpr int PROF_SECTIONS = 12;
+struct Prof {
+    unsigned long long t[PROF_SECTIONS], l[PROF_SECTIONS], n[PROF_SECTIONS], last;
+    __device__ __forceinline__ void begin() { for (int k = 0; k < PROF_SECTIONS; k++) { t[k] = 0; l[k] = 0; n[k] = 0; } last = clock64(); }
+    // the time since the last mark belongs to section k; `lanes`: ballot of the lanes that had work in it
+    __device__ __forceinline__ void mark(int k, unsigned long long lanes)
+    {
+        const unsigned long long now = clock64();
+        if (lanes != 0ull) { t[k] += now - last; l[k] += (unsigned long long)__popcll(lanes); n[k] += 1; }
+        else t[PROF_SECTIONS - 1] += now - last;      // nobody needed it: the loop's own overhead
+        last = clock64();
+    }
+};
+#else
+struct Prof {
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void mark(int, unsigned long long) {}
+};
+#endif
+
 // 64-byte LBVH node: both children's boxes plus two links (>= 0 inner node, < 0 ~shape).
 struct LbvhNode {
     float lmin[3], lmax[3];
@@ -1005,19 +1029,30 @@ __device__ __forceinline__ bool lbvh_step(const SceneView& sv, const Ray& r, flo
 // shared walk 49.1 -> 43.4 at 12; RTNW final, tiles, 66.0 -> 61.0 at 16; 2 M triangles 3840x2160x16
 // 58.2 -> 54.6 at 8 (a 1000-triangle mesh loses: 83.7 -> 98.5; such meshes keep 1).
 // `walking`: this lane still has steps to take; returns true when its walk has ended.
+constexpr int PROF_NODE = 0, PROF_LEAF = 1;
+template <uint32_t F>
+__device__ __forceinline__ bool lbvh_voted_step(const SceneView& sv, const Ray& r, float tmin, float tmax, LbvhWalk& w, int* stack, int* spill,
+                                                bool walking, Prof& pf)
+{
+    const bool at_leaf = walking && w.cur < 0, at_node = walking && w.cur >= 0;
+    const unsigned long long leaf_lanes = __ballot(at_leaf), node_lanes = __ballot(at_node);
+    const int leaves = __popcll(leaf_lanes);
+    const bool nodes_left = node_lanes != 0ull;
+    bool ended = false;
+    if (at_node) ended = lbvh_node_step<F>(sv, r, tmin, tmax, w, stack, spill);
+    pf.mark(PROF_NODE, node_lanes);
+    if (leaves >= sv.leaf_vote || !nodes_left) {
+        if (at_leaf) ended = lbvh_leaf_step<F>(sv, r, tmin, tmax, w, stack, spill);
+        pf.mark(PROF_LEAF, leaf_lanes);
+    }
+    return ended;
+}
 template <uint32_t F>
 __device__ __forceinline__ bool lbvh_voted_step(const SceneView& sv, const Ray& r, float tmin, float tmax, LbvhWalk& w, int* stack, int* spill,
                                                 bool walking)
 {
-    const bool at_leaf = walking && w.cur < 0, at_node = walking && w.cur >= 0;
-    const int leaves = __popcll(__ballot(at_leaf));
-    const bool nodes_left = __ballot(at_node) != 0ull;
-    bool ended = false;
-    if (at_node) ended = lbvh_node_step<F>(sv, r, tmin, tmax, w, stack, spill);
-    if (leaves >= sv.leaf_vote || !nodes_left) {
-        if (at_leaf) ended = lbvh_leaf_step<F>(sv, r, tmin, tmax, w, stack, spill);
-    }
-    return ended;
+    Prof none;
+    return lbvh_voted_step<F>(sv, r, tmin, tmax, w, stack, spill, walking, none);
 }
 template <uint32_t F>
 __device__ __forceinline__ bool lbvh_t(const SceneView& sv, const Ray& r, float tmin, float tmax,

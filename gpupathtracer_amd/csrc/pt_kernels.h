@@ -14,7 +14,10 @@
 
 template <uint32_t F, class W>
 struct FusedLaunch {
-    static void render(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st);
+    // chunk_rec: five 64-bit words per pixel, all zero at launch, when the persistent-lane schedules trace a pixel's
+    // samples in chunks (ra.n_chunks > 1 with ra.refill != 0); fault: raised when a lane gives up waiting for a record
+    static void render(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, unsigned long long* chunk_rec, int* fault,
+                       hipStream_t st);
     // words: [0] the ticket counter, [1 ..] one progress word per group of four wave tiles, all zero at launch
     static void chunks(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault, hipStream_t st);
     static void pass(const ptd::SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume, hipStream_t st);

@@ -16,6 +16,32 @@ using namespace ptk;
 
 // ---- kernels ----------------------------------------------------------------------------------------
 
+#ifdef PT_PROFILE
+// Section sums of every wave of the profiled translation unit's kernels (see Prof): ticks, lanes, runs per section.
+__device__ unsigned long long g_prof[3 * PROF_SECTIONS];
+__device__ __forceinline__ void prof_flush(const Prof& pf)
+{
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < PROF_SECTIONS; k++) {
+            atomicAdd(&g_prof[3 * k + 0], pf.t[k]); atomicAdd(&g_prof[3 * k + 1], pf.l[k]); atomicAdd(&g_prof[3 * k + 2], pf.n[k]);
+        }
+}
+extern "C" int pt_debug_profile(unsigned long long* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long zero[3 * PROF_SECTIONS] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero)) != hipSuccess) return -1; }
+    return PROF_SECTIONS;
+}
+#else
+__device__ __forceinline__ void prof_flush(const Prof&) {}
+#endif
+#ifdef PT_PROFILE
+#define PROF_LANES(name, cond) const unsigned long long name = __ballot(cond)
+#else
+#define PROF_LANES(name, cond) constexpr unsigned long long name = 0ull
+#endif
+constexpr int PROF_SHADE = 2, PROF_PIXEL = 3, PROF_RECORD = 4, PROF_CAMERA = 5, PROF_WALK_HIT = 6, PROF_END = 7;
+
 // Workgroups per CU the fused kernels are compiled for (a register cap; one workgroup is one wave per
 // SIMD).  The compiler's free choice leaves the rectangle-scene kernel at 5 waves per SIMD and the
 // full-feature kernels at 2.  Measured on MI355X (kernel ms): rectangle scene 1024^2 x512 at 5/6/7/8 =
@@ -73,9 +99,10 @@ __device__ __forceinline__ void lane_begin_pixel(LaneState& st, const RenderArgs
 }
 
 // One bounce of the pixel's sample loop.  Returns true when the pixel's last sample has ended.
+// `ns_end`: the sample count at which the lane's work item ends (the pixel's last sample, or the end of a chunk).
 template <uint32_t F, class W>
 __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs& ra, LaneState& st, const Rcp& fnx, const Rcp& fny,
-                                          int* my_stack, const float4* faces)
+                                          int* my_stack, const float4* faces, int ns_end)
 {
     if (st.fresh) {                                       // render_pixel, src/ptMain.cu:158-160
         // (x + rand) / nx: the numerator is 0 or at least 2^-32 and the frame size at most 2^31, inside
@@ -108,7 +135,7 @@ __device__ __forceinline__ bool lane_step(const SceneView& sv, const RenderArgs&
         st.accum = st.accum + st.thr;
         st.s++;
         st.fresh = true;
-        return st.s >= ra.ns;
+        return st.s >= ns_end;
     }
     return false;
 }
@@ -153,7 +180,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_tiles(Scene
     lane_init(st);
     unsigned i;
     lane_begin_pixel(st, ra, x, ytop, i);
-    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces)) {}
+    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces, ra.ns)) {}
     lane_write_pixel(st, ra, i, out);
 }
 
@@ -189,7 +216,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
         st.accum = mk(a.sum[0], a.sum[1], a.sum[2]);
         st.s = first;
     }
-    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces)) {}      // ra.ns = first + count for this launch
+    while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces, ra.ns)) {}      // ra.ns = first + count for this launch
     PtAccumPixel a;
     a.rng_lo = (uint32_t)st.rng.state; a.rng_hi = (uint32_t)(st.rng.state >> 32);
     a.sum[0] = st.accum.x; a.sum[1] = st.accum.y; a.sum[2] = st.accum.z;
@@ -280,9 +307,8 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
                 st.accum = mk(out[3 * (size_t)i + 0], out[3 * (size_t)i + 1], out[3 * (size_t)i + 2]);
                 st.s = c * ra.chunk_samples;
             }
-            RenderArgs part = ra;                             // this item's samples end where the next chunk begins
-            part.ns = min(ra.ns, (c + 1) * ra.chunk_samples);
-            while (!lane_step<F, W>(sv, part, st, fnx, fny, my_stack, faces)) {}
+            const int ns_end = min(ra.ns, (c + 1) * ra.chunk_samples);     // this item's samples end where the next chunk begins
+            while (!lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces, ns_end)) {}
             if (c == ra.n_chunks - 1) {
                 lane_write_pixel(st, ra, i, out);
             } else {
@@ -296,6 +322,64 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
     }
 }
 
+// ---- a pixel's samples in chunks under the persistent-lane schedules ----------------------------------------
+// With one slot per pixel a launch of few pixels and many samples ends pixel by pixel: the lanes that drew the last
+// slots trace all of their samples while the rest of the GPU has run dry (random spheres 1920x1080 at 1024 samples:
+// five pixels per lane, a tenth of the launch spent that way).  So a slot is (chunk, pixel), numbered chunk-major, and
+// a lane traces one chunk of a pixel's samples.  The samples stay one sequence (src/ptMain.cu:156-162): between
+// chunks the pixel's random-stream state and running sum wait in a record of five 64-bit words, each word a
+// payload in its low half and the number of chunks finished in its high half, written and read with relaxed
+// atomics.  A reader takes the record only when all five words carry the count it needs, so no fence -- which on
+// this part writes back or invalidates a whole L2 -- orders the words: a torn read is simply read again.  The lane
+// that drew (c, pixel) usually finds chunk c - 1 long finished (it was drawn a whole sweep of the frame earlier);
+// when not, the lane keeps the slot and asks again on its next round while the other lanes of its wave carry on
+// (the lane that holds chunk c - 1 may be one of them), so nothing spins with a wave's lanes masked off.  The wait
+// ends: chunk c - 1 was drawn earlier, so a running lane holds it, and the chain of waits ends at a chunk 0.  It is
+// bounded all the same (*fault = 2, the host reports the frame as invalid).  Records are zeroed by the host before
+// every launch.
+constexpr int CHUNK_REC_WORDS = 5;
+// A lane waits at most this long for one record (ticks of the 100 MHz wall clock; the low 32 bits wrap after 42.9 s).
+// Far beyond any chunk the library cuts itself; a caller who asks for chunks that take a lane longer has asked for too much.
+#ifndef PT_CHUNK_WAIT_TICKS
+#define PT_CHUNK_WAIT_TICKS 3000000000u
+#endif
+constexpr unsigned CHUNK_WAIT_TICKS = PT_CHUNK_WAIT_TICKS;
+__device__ __forceinline__ unsigned clock_ticks() { return (unsigned)wall_clock64(); }
+__device__ __forceinline__ void chunk_record_store(unsigned long long* __restrict__ rec, unsigned i, const LaneState& st, unsigned done)
+{
+    unsigned long long* r = rec + (size_t)CHUNK_REC_WORDS * i;
+    const unsigned long long tag = (unsigned long long)done << 32;
+    __hip_atomic_store(&r[0], tag | (uint32_t)st.rng.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&r[1], tag | (uint32_t)(st.rng.state >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&r[2], tag | (uint32_t)__float_as_uint(st.accum.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&r[3], tag | (uint32_t)__float_as_uint(st.accum.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&r[4], tag | (uint32_t)__float_as_uint(st.accum.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true when the record holds the state after `done` chunks; st then continues from there
+__device__ __forceinline__ bool chunk_record_load(unsigned long long* __restrict__ rec, unsigned i, LaneState& st, unsigned done)
+{
+    unsigned long long* r = rec + (size_t)CHUNK_REC_WORDS * i;
+    const unsigned long long w0 = __hip_atomic_load(&r[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(&r[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w2 = __hip_atomic_load(&r[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w3 = __hip_atomic_load(&r[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w4 = __hip_atomic_load(&r[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool whole = (unsigned)(w0 >> 32) == done && (unsigned)(w1 >> 32) == done && (unsigned)(w2 >> 32) == done &&
+                       (unsigned)(w3 >> 32) == done && (unsigned)(w4 >> 32) == done;
+    if (whole) {
+        st.rng.state = (w0 & 0xffffffffull) | (w1 << 32);
+        st.accum = mk(__uint_as_float((unsigned)w2), __uint_as_float((unsigned)w3), __uint_as_float((unsigned)w4));
+    }
+    return whole;
+}
+// Slot -> (chunk, pixel slot of the shard): chunk-major, so that every pixel's chunk c is handed out before any
+// pixel's chunk c + 1.  n_chunks <= 1: the slot is the pixel slot.
+__device__ __forceinline__ void slot_chunk(const RenderArgs& ra, unsigned total_slots, unsigned slot, unsigned& c, unsigned& pixel_slot)
+{
+    c = 0; pixel_slot = slot;
+    if (ra.n_chunks > 1) { c = slot / total_slots; pixel_slot = slot - c * total_slots; }
+}
+
 // Fused scheduler with persistent lanes: a lane that has finished its pixel takes the next pixel
 // slot of the shard (slots are numbered tile by tile, 64 per 8x8 wave tile) from a device counter,
 // so a wave stays full until the shard runs out.  Pays when the closest-hit search, whose loop is
@@ -303,7 +387,8 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
 // pixel's random stream is seeded by its index (src/ptMain.cu:178-184).
 template <uint32_t F, class W>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(SceneView sv, RenderArgs ra, float* __restrict__ out,
-                                                       unsigned* __restrict__ next_slot)
+                                                       unsigned* __restrict__ next_slot, unsigned long long* __restrict__ chunk_rec,
+                                                       int* __restrict__ fault)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[FaceTable<F, W>::float4s];
@@ -312,13 +397,17 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
     const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
+    const unsigned all_slots = total_slots * (unsigned)max(1, ra.n_chunks);       // the host keeps this below 2^32
     const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
     LaneState st;
     lane_init(st);
     unsigned i = 0;
+    int ns_end = ra.ns;
+    unsigned need_chunks = 0, wait_from = 0;          // need_chunks > 0: the slot is held, the record of the pixel's earlier chunks is not there yet
     bool have = false;
     while (true) {
-        if (!have) {
+        const bool wave_busy = __ballot(have) != 0ull;
+        if (!have && need_chunks == 0) {
             const unsigned long long need = __ballot(1);  // one atomic per wave for all lanes that ran dry
             const int leader = __ffsll((long long)need) - 1;
             unsigned base = 0;
@@ -326,14 +415,24 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
             base = __shfl(base, leader);
             const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const unsigned slot = base + (unsigned)__popcll(need & lower);
-            if (slot >= total_slots) break;               // the shard is exhausted: this lane is done
+            if (slot >= all_slots) break;                 // the shard is exhausted: this lane is done
+            unsigned c, ps;
+            slot_chunk(ra, total_slots, slot, c, ps);
             int x, ytop;
-            if (!wave_pixel(ra, (int)(slot >> 6), (int)(slot & 63), x, ytop)) continue;   // slot beyond the image edge
+            if (!wave_pixel(ra, (int)(ps >> 6), (int)(ps & 63), x, ytop)) continue;   // slot beyond the image edge
             lane_begin_pixel(st, ra, x, ytop, i);
-            have = true;
+            ns_end = ra.n_chunks > 1 ? min(ra.ns, (int)(c + 1) * ra.chunk_samples) : ra.ns;
+            if (c > 0) { need_chunks = c; wait_from = clock_ticks(); st.s = (int)c * ra.chunk_samples; }
+            else have = true;
         }
-        if (lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces)) {
-            lane_write_pixel(st, ra, i, out);
+        if (need_chunks > 0) {
+            if (chunk_record_load(chunk_rec, i, st, need_chunks)) { need_chunks = 0; have = true; }
+            else if (clock_ticks() - wait_from > CHUNK_WAIT_TICKS) { *fault = 2; break; }
+            else { if (!wave_busy) __builtin_amdgcn_s_sleep(32); continue; }      // nobody in this wave has work: ease off the memory system
+        }
+        if (lane_step<F, W>(sv, ra, st, fnx, fny, my_stack, faces, ns_end)) {
+            if (ns_end >= ra.ns) lane_write_pixel(st, ra, i, out);
+            else chunk_record_store(chunk_rec, i, st, (unsigned)(ns_end / ra.chunk_samples));
             have = false;
         }
     }
@@ -369,7 +468,8 @@ __device__ __attribute__((noinline)) ListWalkHit list_walk_out_of_line(const Sce
 // computes, and the order of its random draws, is unchanged (the search draws none).
 template <uint32_t F>
 __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneView sv, RenderArgs ra, float* __restrict__ out,
-                                                                           unsigned* __restrict__ next_slot)
+                                                                           unsigned* __restrict__ next_slot, unsigned long long* __restrict__ chunk_rec,
+                                                                           int* __restrict__ fault)
 {
     static_assert((F & F_LBVH) != 0, "the shared walk is the LBVH walk");
     __shared__ int lds_stack[4 * 64 * LBVH_LDS_STACK];
@@ -377,8 +477,11 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane];
     const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
+    const unsigned all_slots = total_slots * (unsigned)max(1, ra.n_chunks);       // the host keeps this below 2^32
     const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
-    enum { NEED_PIXEL, NEXT_RAY, WALKING, WALKED, DONE };
+    enum { NEED_PIXEL, NEED_RECORD, NEXT_RAY, WALKING, WALKED, DONE };
+    int ns_end = ra.ns;                                       // where this lane's work item ends: the pixel's last sample or a chunk's
+    unsigned wait_from = 0;
     LaneState st;
     lane_init(st);
     LbvhWalk w;
@@ -386,7 +489,10 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
     int spill[LBVH_STACK - LBVH_LDS_STACK];
     unsigned i = 0;
     int mode = NEED_PIXEL;
+    Prof pf;
+    pf.begin();
     while (true) {
+        PROF_LANES(walked_lanes, mode == WALKED);
         if (mode == WALKED) {                                 // the rest of the bounce, as in lane_step
             Hit h;
             h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
@@ -434,9 +540,15 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
                 st.accum = st.accum + st.thr;
                 st.s++;
                 st.fresh = true;
-                if (st.s >= ra.ns) { lane_write_pixel(st, ra, i, out); mode = NEED_PIXEL; }
+                if (st.s >= ns_end) {
+                    if (ns_end >= ra.ns) lane_write_pixel(st, ra, i, out);
+                    else chunk_record_store(chunk_rec, i, st, (unsigned)(ns_end / ra.chunk_samples));
+                    mode = NEED_PIXEL;
+                }
             }
         }
+        pf.mark(PROF_SHADE, walked_lanes);
+        PROF_LANES(pixel_lanes, mode == NEED_PIXEL);
         if (mode == NEED_PIXEL) {
             const unsigned long long need = __ballot(1);      // one atomic per wave for all lanes that ran dry
             const int leader = __ffsll((long long)need) - 1;
@@ -445,11 +557,26 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             base = __shfl(base, leader);
             const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const unsigned slot = base + (unsigned)__popcll(need & lower);
+            unsigned c, ps;
+            slot_chunk(ra, total_slots, slot, c, ps);
             int x, ytop;
-            if (slot >= total_slots) mode = DONE;             // the shard is exhausted
-            else if (wave_pixel(ra, (int)(slot >> 6), (int)(slot & 63), x, ytop)) { lane_begin_pixel(st, ra, x, ytop, i); mode = NEXT_RAY; }
+            if (slot >= all_slots) mode = DONE;               // the shard is exhausted
+            else if (wave_pixel(ra, (int)(ps >> 6), (int)(ps & 63), x, ytop)) {
+                lane_begin_pixel(st, ra, x, ytop, i);
+                ns_end = ra.n_chunks > 1 ? min(ra.ns, (int)(c + 1) * ra.chunk_samples) : ra.ns;
+                mode = NEXT_RAY;
+                if (c > 0) { st.s = (int)c * ra.chunk_samples; st.depth = (int)c; wait_from = clock_ticks(); mode = NEED_RECORD; }    // depth is free until the first ray
+            }
             // else: a slot beyond the image edge; ask again next round
         }
+        pf.mark(PROF_PIXEL, pixel_lanes);
+        PROF_LANES(record_lanes, mode == NEED_RECORD);
+        if (mode == NEED_RECORD) {                            // the state the pixel's earlier chunks left; not there yet: ask again next round
+            if (chunk_record_load(chunk_rec, i, st, (unsigned)st.depth)) mode = NEXT_RAY;
+            else if (clock_ticks() - wait_from > CHUNK_WAIT_TICKS) { *fault = 2; mode = DONE; }
+        }
+        pf.mark(PROF_RECORD, record_lanes);
+        PROF_LANES(ray_lanes, mode == NEXT_RAY);
         if (mode == NEXT_RAY) {
             if (st.fresh) {                                   // render_pixel, src/ptMain.cu:158-160
                 float u = quot((float)st.x + st.rng.rand(), fnx);
@@ -462,14 +589,18 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             lbvh_begin(sv, st.ray, FLT_MAX, w);
             mode = WALKING;
         }
-        const int live = __popcll(__ballot(mode != DONE));
-        if (live == 0) break;
+        pf.mark(PROF_CAMERA, ray_lanes);
+        if (__ballot(mode != DONE) == 0ull) break;
+        // lanes that have something to do once the wave leaves the search loop; a lane waiting for a record has not
+        // (counted, a wave of mostly waiting lanes would leave the loop at once, every round, and never step the rest)
+        const int live = __popcll(__ballot(mode != DONE && mode != NEED_RECORD));
         while (true) {
             const int walking = __popcll(__ballot(mode == WALKING));
             if (walking == 0 || live - walking >= ra.walk_wait) break;
-            if (lbvh_voted_step<F>(sv, st.ray, 0.001f, FLT_MAX, w, my_stack, spill, mode == WALKING)) mode = WALKED;
+            if (lbvh_voted_step<F>(sv, st.ray, 0.001f, FLT_MAX, w, my_stack, spill, mode == WALKING, pf)) mode = WALKED;
         }
     }
+    prof_flush(pf);
 }
 
 template <uint32_t F, class W>
@@ -495,7 +626,8 @@ __global__ __launch_bounds__(256) void k_trace_closest(SceneView sv, const PtRay
 
 // Launchers of one specialisation.
 template <uint32_t F, class W>
-void FusedLaunch<F, W>::render(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, hipStream_t st)
+void FusedLaunch<F, W>::render(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, unsigned long long* chunk_rec, int* fault,
+                               hipStream_t st)
 {
     // REFILL: persistent grid of at most 32 waves per CU, the rest of the shard comes from the counter.
     // A world in the LBVH is searched by the wave-shared walk (which ends a path at the bounce
@@ -504,8 +636,8 @@ void FusedLaunch<F, W>::render(const SceneView& sv, const RenderArgs& ra, float*
     const int tiles4 = (ra.n_wave_tiles + 3) / 4;
     const dim3 block(256), grid(refill ? std::min(tiles4, 2048) : tiles4);
     if (ra.refill == 2) {
-        if constexpr ((F & F_LBVH) != 0) hipLaunchKernelGGL((k_render_walk<F>), grid, block, 0, st, sv, ra, out, next_slot);
-    } else if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot);
+        if constexpr ((F & F_LBVH) != 0) hipLaunchKernelGGL((k_render_walk<F>), grid, block, 0, st, sv, ra, out, next_slot, chunk_rec, fault);
+    } else if (refill) hipLaunchKernelGGL((k_render_refill<F, W>), grid, block, 0, st, sv, ra, out, next_slot, chunk_rec, fault);
     else hipLaunchKernelGGL((k_render_tiles<F, W>), grid, block, 0, st, sv, ra, out);
 }
 template <uint32_t F, class W>

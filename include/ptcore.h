@@ -113,7 +113,13 @@ enum PtSchedule {
                              * few tiles for the GPU and many samples), REFILL for reference BVHs walked as
                              * they are and for lists of more than 16 objects                                   */
     PT_SCHEDULE_TILES  = 1, /* one 8x8 tile per wave, one pixel per lane                                 */
-    PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter                */
+    PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter.  When the shard holds
+                             * more pixels than the GPU has lanes, REFILL and WALK hand out (chunk of samples, pixel)
+                             * pairs instead of pixels, chunk by chunk, so that the launch does not end pixel by
+                             * pixel: the pixel's random stream and running sum wait in device memory between its
+                             * chunks (40 bytes per pixel, kept with the scene), the samples stay the one sequence
+                             * of src/ptMain.cu:156-162.  PtRenderParams.chunk_samples: 0 = the library cuts,
+                             * >= ns = never; pt_render_device_noalloc and captured streams never cut.           */
     PT_SCHEDULE_WALK   = 3, /* REFILL, and the wave shares the closest-hit search one tree step at a time:
                              * lanes whose search has ended shade and start their next search while the
                              * others keep walking.  Worlds in the library's LBVH (PT_ACCEL_LBVH) with
@@ -225,7 +231,7 @@ typedef struct PtRenderParams {
      * be added and finished once with pt_frame_finish_device.  Fused pipeline only. */
     int32_t batch_index, batch_count;
     int32_t raw_sum;
-    int32_t chunk_samples; /* PT_SCHEDULE_CHUNKS: samples per chunk; 0 = the library's choice */
+    int32_t chunk_samples; /* PT_SCHEDULE_CHUNKS, _REFILL, _WALK (and what AUTO picks): samples per chunk; 0 = the library's choice */
     int32_t reserved[2];
 } PtRenderParams;
 
@@ -254,7 +260,7 @@ typedef struct PtRenderStats {
     int32_t  schedule;       /* PtSchedule the fused pipeline ran (TILES or REFILL), else 0 */
     int32_t  signature_walk; /* 1 when the world list matched a compiled-in signature (straight-line walk) */
     int32_t  kernel_family;  /* PtKernelFamily: which compiled specialisation of the radiance kernels ran */
-    int32_t  reserved0;
+    int32_t  n_chunks;       /* chunks every pixel's samples were cut into (CHUNKS, or REFILL / WALK on a large shard); 0 = not cut */
     uint64_t reserved[2];
 } PtRenderStats;
 

@@ -1179,6 +1179,49 @@ def test_shared_walk_schedule_bit_exact(oracle, which):
     assert_bit_exact(sc.render(8, 8, 2, 0), oracle.render(d, 8, 8, 2, 0), which + " depth 0 under AUTO")
 
 
+@pytest.mark.parametrize("which", ["random", "cornell", "final", "final_tree", "trimesh"])
+def test_persistent_lane_schedules_in_chunks_bit_exact(oracle, which):
+    """REFILL and WALK with every pixel's samples cut into chunks: slots are (chunk, pixel), the pixel's random
+    stream and running sum wait in a record between chunks.  Where the cuts fall changes no sample: chunks of one
+    sample, sizes that do not divide the count, a frame so small that the lane holding a pixel's previous chunk
+    sits in the same wave as the lane that drew the next one, shards, and the library's own cuts on a frame with
+    more pixels than the GPU has lanes."""
+    if which == "trimesh":
+        d = pt.trimesh_scene(12, 1.0)
+        d.c.accel = abi.ACCEL_LBVH
+        schedules = (abi.SCHEDULE_WALK, abi.SCHEDULE_REFILL)
+    elif which == "random":
+        d = pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)
+        schedules = (abi.SCHEDULE_WALK, abi.SCHEDULE_REFILL)
+    elif which == "final_tree":
+        d = pt.builtin_scene("final", 16 / 9, earth_rgb=_earth_map_512x256(), accel=abi.ACCEL_LBVH)
+        schedules = (abi.SCHEDULE_REFILL,)
+    else:
+        d = pt.builtin_scene(which, 16 / 9 if which == "final" else 1.0)
+        schedules = (abi.SCHEDULE_REFILL,)
+    sc = pt.Scene(d)
+    for nx, ny, ns in ((72, 40, 7), (8, 8, 9), (3, 2, 5)):
+        ref = oracle.render(d, nx, ny, ns)
+        for schedule in schedules:
+            for chunk in (1, 2, 3, ns - 1):
+                img = sc.render(nx, ny, ns, schedule=schedule, chunk_samples=chunk)
+                assert_bit_exact(img, ref, "%s %dx%dx%d schedule %d in chunks of %d" % (which, nx, ny, ns, schedule, chunk))
+                assert sc.stats().n_chunks == (ns + chunk - 1) // chunk and sc.stats().schedule == schedule
+            assert_bit_exact(sc.render(nx, ny, ns, schedule=schedule, chunk_samples=ns), ref, "uncut")
+            assert sc.stats().n_chunks == 0
+    ref = oracle.render(d, 72, 40, 7, shard_index=1, shard_count=3)
+    assert_bit_exact(sc.render(72, 40, 7, schedule=schedules[0], chunk_samples=2, shard_index=1, shard_count=3), ref, which + " shard in chunks")
+    # more than one and a half times as many pixels as the GPU has lanes (6 waves on each of 1024 SIMDs): the library
+    # cuts by itself -- REFILL into up to 8 chunks, WALK into 4 of at least 32 samples, and not at all with triangles
+    nx, ny, ns = 1024, 640, 128 if schedules[0] == abi.SCHEDULE_WALK else 32
+    whole = sc.render(nx, ny, ns, schedule=schedules[0], chunk_samples=ns)
+    assert sc.stats().n_chunks == 0
+    cut = sc.render(nx, ny, ns, schedule=schedules[0])
+    assert sc.stats().n_chunks == (0 if which == "trimesh" else 4 if schedules[0] == abi.SCHEDULE_WALK else 8)
+    assert_bit_exact(cut, whole, which + " %dx%dx%d, the library's cuts" % (nx, ny, ns))
+    assert_bit_exact(sc.render(nx, ny, ns, schedule=schedules[0], chunk_samples=5), whole, which + " %dx%dx%d in chunks of 5" % (nx, ny, ns))
+
+
 def test_shared_walk_needs_the_lbvh():
     sc = pt.Scene(pt.builtin_scene("cornell", 1.0))
     with pytest.raises(pt.PtError) as e:

@@ -13,8 +13,8 @@ accel = abi.ACCEL_LBVH if "lbvh" in rest else abi.ACCEL_LBVH_BINARY if "binary" 
 kw = {}
 if "schedule" in rest:
     kw["schedule"] = int(rest[rest.index("schedule") + 1])
-if "chunk" in rest:
-    kw["schedule"] = abi.SCHEDULE_CHUNKS
+if "chunk" in rest:                       # with `schedule 2|3`: the persistent-lane schedules in chunks of that many samples (>= spp: never)
+    kw.setdefault("schedule", abi.SCHEDULE_CHUNKS)
     kw["chunk_samples"] = int(rest[rest.index("chunk") + 1])
 if "wavefront" in rest:
     kw["pipeline"] = abi.PIPELINE_WAVEFRONT
@@ -36,5 +36,5 @@ for _ in range(3):
     pt.synchronize()
     ms.append(sc.stats().kernel_ms)
 st = sc.stats()
-print("%s %dx%dx%d %s: %.3f ms  %.0f Mpaths/s  (schedule %d, signature %d, all %s)" %
-      (name, nx, ny, spp, " ".join(rest), min(ms), st.paths / min(ms) / 1e3, st.schedule, st.signature_walk, ["%.2f" % m for m in ms]))
+print("%s %dx%dx%d %s: %.3f ms  %.0f Mpaths/s  (schedule %d, chunks %d, signature %d, all %s)" %
+      (name, nx, ny, spp, " ".join(rest), min(ms), st.paths / min(ms) / 1e3, st.schedule, st.n_chunks, st.signature_walk, ["%.2f" % m for m in ms]), flush=True)
