@@ -109,7 +109,7 @@ EXPORTS = [
     "pt_trace_closest", "pt_render_stats", "pt_render_on_devices", "pt_frame_finish_device", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
     "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_lbvh_form", "pt_scene_lbvh_wide_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",
-    "pt_median_filter", "pt_median_filter_device", "pt_device_count",
+    "pt_median_filter", "pt_median_filter_device", "pt_image_decode_jpeg", "pt_device_count",
     "pt_set_device", "pt_device_synchronize", "pt_device_malloc", "pt_device_free", "pt_memcpy_to_host",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_reduce_frame", "pt_comm_barrier", "pt_comm_allreduce_max_f64", "pt_comm_destroy", "pt_libm_eval",
 ]

@@ -56,6 +56,7 @@ def library():
                                           P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
+    lib.pt_image_decode_jpeg.argtypes = [C.c_char_p, C.c_size_t, P(C.c_int32), P(C.c_int32), C.c_void_p, C.c_size_t]
     lib.pt_scene_desc_free.restype = None
     lib.pt_render_on_devices.argtypes = [P(A.PtSceneDesc), P(A.PtRenderParams), P(C.c_int32), C.c_int32, C.c_void_p]
     lib.pt_frame_finish_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
@@ -98,6 +99,17 @@ def device_count():
 
 def set_device(index):
     _check(library().pt_set_device(int(index)))
+
+
+def decode_jpeg(data):
+    """A baseline JPEG file (bytes) -> (ny, nx, 3) uint8 texels, as the reference's stbi_load decodes it."""
+    lib = library()
+    blob = bytes(data)
+    nx, ny = C.c_int32(0), C.c_int32(0)
+    _check(lib.pt_image_decode_jpeg(blob, len(blob), C.byref(nx), C.byref(ny), None, 0))
+    out = np.empty((ny.value, nx.value, 3), np.uint8)
+    _check(lib.pt_image_decode_jpeg(blob, len(blob), C.byref(nx), C.byref(ny), out.ctypes.data, out.nbytes))
+    return out
 
 
 def synchronize():

@@ -34,7 +34,7 @@ int fail(const char* what)
     return EXIT_FAILURE;
 }
 
-// Texels for the final scene's earth sphere: a binary PPM (P6, maxval 255), or the word "synthetic" for a
+// Texels for the final scene's earth sphere: a baseline JPEG (what the reference loads), a binary PPM (P6, maxval 255), or the word "synthetic" for a
 // fixed 512x256 pattern (the size of the reference's earthmap.jpg; not its content).
 bool load_earthmap(const std::string& arg, std::vector<uint8_t>* texels, int* w, int* h)
 {
@@ -48,11 +48,28 @@ bool load_earthmap(const std::string& arg, std::vector<uint8_t>* texels, int* w,
             }
         return true;
     }
+    {
+        // a JPEG file, as the reference reads (stbi_load("earthmap.jpg", ...), src/ptMain.cu:399): decoded by the library
+        std::ifstream jf(arg, std::ios::binary);
+        unsigned char head[2] = { 0, 0 };
+        if (jf && jf.read(reinterpret_cast<char*>(head), 2) && head[0] == 0xFF && head[1] == 0xD8) {
+            jf.seekg(0, std::ios::end);
+            std::vector<char> file((size_t)jf.tellg());
+            jf.seekg(0);
+            jf.read(file.data(), (std::streamsize)file.size());
+            int32_t jw = 0, jh = 0;
+            if (pt_image_decode_jpeg(file.data(), file.size(), &jw, &jh, nullptr, 0) != PT_OK) { std::cerr << "--earthmap: " << arg << ": " << pt_last_error() << std::endl; return false; }
+            texels->resize((size_t)3 * jw * jh);
+            if (pt_image_decode_jpeg(file.data(), file.size(), &jw, &jh, texels->data(), texels->size()) != PT_OK) { std::cerr << "--earthmap: " << pt_last_error() << std::endl; return false; }
+            *w = jw; *h = jh;
+            return true;
+        }
+    }
     std::ifstream f(arg, std::ios::binary);
     std::string magic;
     int maxval = 0;
     if (!f || !(f >> magic >> *w >> *h >> maxval) || magic != "P6" || maxval != 255 || *w <= 0 || *h <= 0 || (long)*w * *h > (1L << 26)) {
-        std::cerr << "--earthmap: " << arg << " is not a binary PPM (P6, maxval 255)" << std::endl;
+        std::cerr << "--earthmap: " << arg << " is neither a JPEG nor a binary PPM (P6, maxval 255)" << std::endl;
         return false;
     }
     f.get();                                     // the single whitespace byte after maxval
@@ -107,7 +124,7 @@ int main(int argc, char** argv)
                          "              [--scene simple_spheres|simple_light|random|cornell|cornell_spheres|final|trimesh]\n"
                          "              [--gpus N] [--accel auto|list|lbvh] [--pipeline fused|wavefront]\n"
                          "              [--stream-in scene.bin] [--stream-out scene.bin] [--pass-samples K] [-m]\n"
-                         "              [--earthmap map.ppm|synthetic]   (scene final: texels of the earth sphere)" << std::endl;
+                         "              [--earthmap map.jpg|map.ppm|synthetic]   (scene final: texels of the earth sphere)" << std::endl;
             return EXIT_FAILURE;
         }
     }

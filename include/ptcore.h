@@ -429,6 +429,14 @@ int  pt_median_filter(const float* in_rgb, float* out_rgb, int32_t nx, int32_t n
 int  pt_median_filter_device(const void* d_in_rgb, void* d_out_rgb, int32_t nx, int32_t ny, int32_t size,
                              void* hip_stream);
 
+/* stbi_load("earthmap.jpg", &nx, &ny, &nz, 0) of the reference's final() (src/ptMain.cu:396-402; vendored
+ * src/stb_image.h v2.15): a sequential (baseline) JPEG file in memory to nx*ny RGB8 texels, row 0 on top, the
+ * bytes that decoder produces (same inverse DCT, chroma filters and colour conversion; a one-component file
+ * comes out grey in three channels).  Call with rgb == NULL for the size, then with nx*ny*3 bytes of room.
+ * Progressive and arithmetic-coded files are PT_ERR_INVALID.  Host only; the texels go into
+ * PtSceneDesc.texels (pt_scene_desc_builtin's earth_rgb). */
+int  pt_image_decode_jpeg(const void* data, size_t bytes, int32_t* nx, int32_t* ny, uint8_t* rgb, size_t capacity);
+
 /* Number of visible HIP devices (0 when there is none); never fails. */
 int  pt_device_count(void);
 

@@ -633,7 +633,12 @@ def test_cli_writes_every_image_format(tmp_path, oracle):
     spec = importlib.util.spec_from_file_location("pt_bench_configs", os.path.join(sys_path_bench, "configs.py"))
     configs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(configs)
-    for arg, texels in ((ppm, tex), ("synthetic", configs.synthetic_earthmap())):
+    # ... and from a JPEG file, the format of the reference's own map (stbi_load, src/ptMain.cu:399), decoded by the library
+    jpg = str(tmp_path / "map.jpg")
+    j, i = np.mgrid[0:40, 0:72]
+    Image.fromarray(np.stack([i * 3, j * 6, (i * j) >> 4], -1).astype(np.uint8)).save(jpg, "JPEG", quality=80, subsampling=2)
+    from gpupathtracer_amd import api
+    for arg, texels in ((ppm, tex), ("synthetic", configs.synthetic_earthmap()), (jpg, api.decode_jpeg(open(jpg, "rb").read()))):
         de = pt.builtin_scene("final", 48 / 32, earth_rgb=texels, accel=abi.ACCEL_LBVH)      # the CLI picks the LBVH for worlds with a BVH
         assert de.c.n_world == 10
         want = np.clip((255.99 * oracle.render(de, 48, 32, 4).astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)
@@ -642,7 +647,7 @@ def test_cli_writes_every_image_format(tmp_path, oracle):
         assert r.returncode == 0, r.stderr
         np.testing.assert_array_equal(np.asarray(Image.open(out).convert("RGB")), want)
     r = subprocess.run([exe, "--scene", "final", "--earthmap", str(tmp_path / "img.png"), "-q"], capture_output=True, text=True)
-    assert r.returncode != 0 and "not a binary PPM" in r.stderr
+    assert r.returncode != 0 and "neither a JPEG nor a binary PPM" in r.stderr
     r = subprocess.run([exe, "--scene", "nope", "-q"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown scene" in r.stderr
 
