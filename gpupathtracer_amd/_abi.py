@@ -85,11 +85,17 @@ class PtRenderParams(C.Structure):
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32),
                 ("pipeline", C.c_int32), ("schedule", C.c_int32), ("batch_index", C.c_int32), ("batch_count", C.c_int32),
-                ("raw_sum", C.c_int32), ("chunk_samples", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("raw_sum", C.c_int32), ("chunk_samples", C.c_int32), ("stage_stats", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PtRay(C.Structure):
     _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("time", C.c_float), ("seed", C.c_uint32)]
+
+
+class PtStageStats(C.Structure):
+    _fields_ = [("groups", C.c_uint64), ("rounds", C.c_uint64), ("extend_lanes", C.c_uint64), ("extend_waves", C.c_uint64),
+                ("shade_lanes", C.c_uint64 * 4), ("shade_waves", C.c_uint64 * 4), ("extend_ticks", C.c_uint64), ("shade_ticks", C.c_uint64),
+                ("timed_groups", C.c_uint64), ("reserved", C.c_uint64)]
 
 
 class PtRenderStats(C.Structure):
@@ -106,7 +112,7 @@ assert C.sizeof(PtRenderParams) == 64
 # Every symbol include/ptcore.h declares.
 EXPORTS = [
     "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device", "pt_render_device_noalloc",
-    "pt_trace_closest", "pt_render_stats", "pt_render_on_devices", "pt_frame_finish_device", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
+    "pt_trace_closest", "pt_render_stats", "pt_render_stage_stats", "pt_render_on_devices", "pt_frame_finish_device", "pt_accum_bytes", "pt_render_pass", "pt_render_progressive",
     "pt_memcpy_to_device", "pt_scene_lbvh_nodes", "pt_scene_lbvh_form", "pt_scene_lbvh_wide_nodes", "pt_scene_desc_builtin",
     "pt_scene_desc_trimesh", "pt_scene_desc_free", "pt_scene_desc_from_stream", "pt_scene_desc_to_stream",
     "pt_median_filter", "pt_median_filter_device", "pt_image_decode_jpeg", "pt_device_count",

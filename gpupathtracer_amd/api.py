@@ -49,6 +49,8 @@ def library():
     lib.pt_render_device_noalloc.argtypes = [C.c_void_p, P(A.PtRenderParams), C.c_void_p, C.c_void_p]
     lib.pt_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.pt_render_stats.argtypes = [C.c_void_p, P(A.PtRenderStats)]
+    if hasattr(lib, "pt_render_stage_stats"):        # (an older build named by PT_LIBPTCORE_PATH for a timing comparison lacks the newer entry points)
+        lib.pt_render_stage_stats.argtypes = [C.c_void_p, P(A.PtStageStats)]
     lib.pt_scene_lbvh_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.pt_scene_lbvh_form.argtypes = [C.c_void_p]
     lib.pt_scene_lbvh_wide_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -56,7 +58,8 @@ def library():
                                           P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_trimesh.argtypes = [C.c_int32, C.c_float, P(P(A.PtSceneDesc))]
     lib.pt_scene_desc_free.argtypes = [P(A.PtSceneDesc)]
-    lib.pt_image_decode_jpeg.argtypes = [C.c_char_p, C.c_size_t, P(C.c_int32), P(C.c_int32), C.c_void_p, C.c_size_t]
+    if hasattr(lib, "pt_image_decode_jpeg"):
+        lib.pt_image_decode_jpeg.argtypes = [C.c_char_p, C.c_size_t, P(C.c_int32), P(C.c_int32), C.c_void_p, C.c_size_t]
     lib.pt_scene_desc_free.restype = None
     lib.pt_render_on_devices.argtypes = [P(A.PtSceneDesc), P(A.PtRenderParams), P(C.c_int32), C.c_int32, C.c_void_p]
     lib.pt_frame_finish_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
@@ -311,10 +314,11 @@ class RenderStats:
 
 
 def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0,
-                batch_index=0, batch_count=0, raw_sum=0, chunk_samples=0):
+                batch_index=0, batch_count=0, raw_sum=0, chunk_samples=0, stage_stats=0):
     return A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=shard_index,
                             shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline, schedule=schedule,
-                            batch_index=batch_index, batch_count=batch_count, raw_sum=raw_sum, chunk_samples=chunk_samples)
+                            batch_index=batch_index, batch_count=batch_count, raw_sum=raw_sum, chunk_samples=chunk_samples,
+                            stage_stats=stage_stats)
 
 
 class Scene:
@@ -378,6 +382,18 @@ class Scene:
         s = A.PtRenderStats()
         _check(library().pt_render_stats(self._h, C.byref(s)))
         return RenderStats(s)
+
+    def stage_stats(self):
+        """Counters of the staged pipeline's most recent render (a dict; see PtStageStats)."""
+        s = A.PtStageStats()
+        _check(library().pt_render_stage_stats(self._h, C.byref(s)))
+        d = {k: int(getattr(s, k)) for k in ("groups", "rounds", "extend_lanes", "extend_waves", "extend_ticks", "shade_ticks", "timed_groups")}
+        d["shade_lanes"] = [int(x) for x in s.shade_lanes]
+        d["shade_waves"] = [int(x) for x in s.shade_waves]
+        d["extend_occupancy"] = d["extend_lanes"] / max(1, 64 * d["extend_waves"])
+        d["shade_occupancy"] = sum(d["shade_lanes"]) / max(1, 64 * sum(d["shade_waves"]))
+        d["extend_time_share"] = d["extend_ticks"] / max(1, d["extend_ticks"] + d["shade_ticks"])
+        return d
 
     def trace_closest(self, rays):
         """rays: structured/packed array of PtRay (n x 32 bytes).  Returns (prim_id int32[n], t float32[n])."""

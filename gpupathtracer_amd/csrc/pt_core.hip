@@ -690,6 +690,7 @@ bool make_args(const PtRenderParams* p, RenderArgs* ra)
         (p->batch_count == 0 && p->batch_index != 0)) return fail("render: batch_index out of range");
     ra->seed_offset = (uint64_t)p->batch_index * (uint64_t)p->nx * (uint64_t)p->ny;
     ra->raw_sum = p->raw_sum ? 1 : 0;
+    ra->stage_stats = p->stage_stats ? 1 : 0;
     return true;
 }
 
@@ -1112,6 +1113,14 @@ extern "C" int pt_render_stats(PtScene* sc, PtRenderStats* stats)
     sc->last.kernel_ms = k;
     sc->last.total_ms = tot;
     *stats = sc->last;
+    return PT_OK;
+}
+
+extern "C" int pt_render_stage_stats(PtScene* sc, PtStageStats* stats)
+{
+    if (!sc || !stats) { pt::set_error("pt_render_stage_stats: null argument"); return PT_ERR_INVALID; }
+    if (!sc->have_stage_stats) { pt::set_error("pt_render_stage_stats: no render on the staged pipeline has run on this scene"); return PT_ERR_INVALID; }
+    *stats = sc->stage_stats;
     return PT_OK;
 }
 

@@ -22,6 +22,7 @@ struct RenderArgs {
     int32_t raw_sum;               // write the plain sample sums instead of sqrt(sum / ns)
     uint64_t seed_offset;          // added to the pixel index before seeding (sample batches; 0 = the reference's stream)
     int32_t chunk_samples, n_chunks;   // chunked tiles: samples per work item and items per tile (0: not chunked)
+    int32_t stage_stats;           // staged scheduler: count what the stages did
 };
 
 // Wave w of the launch -> its 8x8 pixel block.  Shard tiles owned by this shard are
@@ -91,6 +92,8 @@ struct PtScene {
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
     bool have_timing = false;
     PtRenderStats last{};
+    PtStageStats stage_stats{};         // of the most recent render on the staged pipeline
+    bool have_stage_stats = false;
 };
 
 

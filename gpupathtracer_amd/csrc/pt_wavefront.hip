@@ -57,6 +57,7 @@ struct WfState {
     uint64_t* rng;        // PCG state (the increment is (pixel << 1) | 1)
     uint32_t* pix;        // pixel index i = ytop * nx + x
     int*      lost;       // raised by a workgroup that ran out of rounds with lanes still queued
+    unsigned long long* stats;    // PtStageStats as 16 counters, summed over the launch's workgroups (see k_wf_groups)
     int32_t   group_lanes;    // lanes per group: a multiple of 256, at most WF_GROUP_MAX
     int32_t   round_limit;    // rounds after which a group gives up (a lane was lost: cannot happen, must not hang)
 };
@@ -146,11 +147,13 @@ __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& 
 }
 
 // The search: world->hit for the lanes of the group's extend queue `cur`.
-template <uint32_t F, class W>
+template <uint32_t F, class W, bool STATS>
 __device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, float* __restrict__ out,
-                                             int* my_stack, const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first)
+                                             int* my_stack, const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first,
+                                             unsigned* group_stats)
 {
     const unsigned count = gq.n_ext[cur];
+    if constexpr (STATS) { if (threadIdx.x == 0) { atomicAdd(&group_stats[1], 1u); atomicAdd(&group_stats[2], count); atomicAdd(&group_stats[3], (count + 63u) >> 6); } }
     // whole waves iterate together so the ballots in queue_push see every lane of the wave
     for (unsigned it = 0; it < count; it += blockDim.x) {
         const unsigned idx = it + threadIdx.x;
@@ -218,11 +221,12 @@ __device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderAr
 }
 
 // Shading of material queue q: every wave shades one material kind.
-template <uint32_t F, class W>
+template <uint32_t F, class W, bool STATS>
 __device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, int q, float* __restrict__ out,
-                                            const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first)
+                                            const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first, unsigned* group_stats)
 {
     const unsigned count = gq.n_shade[q];
+    if constexpr (STATS) { if (threadIdx.x == 0 && count != 0) { atomicAdd(&group_stats[4 + q], count); atomicAdd(&group_stats[8 + q], (count + 63u) >> 6); } }
     for (unsigned it = 0; it < count; it += blockDim.x) {
         const unsigned idx = it + threadIdx.x;
         const bool active = idx < count;
@@ -279,7 +283,9 @@ __host__ __device__ constexpr int wf_min_blocks(uint32_t F)
 }
 // One workgroup renders one group of lanes, round by round.  Every loop bound below is read from
 // LDS after a barrier, so all lanes of the workgroup take the same trips and meet at every barrier.
-template <uint32_t F, class W>
+// STATS: the kernel also counts what its stages did (PtRenderParams.stage_stats); a kernel of its own because the
+// counting, light as it is, costs the rectangle scene's kernel 6 % of its rate.
+template <uint32_t F, class W, bool STATS>
 __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
 {
     constexpr int NQ = ShadeQueues<F>::value;
@@ -322,18 +328,43 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
     }
     __syncthreads();
 
+    // What the stages did, for pt_render_stage_stats (STATS kernels).  The group's sums live in LDS (the layout of
+    // PtStageStats; 32 bits do: a group's rounds times its lanes stay far below 2^32) and are added to with LDS atomics
+    // whose result nobody waits for, by the stages themselves where they read their queue's length; thread 0 adds them
+    // to the launch's at the end.  The clock is read by one workgroup in 64 only: each read waits for the counter to
+    // come back, and with every workgroup reading it three times a round the rectangle scene's kernel lost a quarter
+    // of its rate.
+    __shared__ unsigned group_stats[STATS ? 12 : 1];
+    __shared__ unsigned long long group_ticks[STATS ? 3 : 1];   // extend, shade, the last reading
+    if constexpr (STATS) {
+        if (threadIdx.x < 12) group_stats[threadIdx.x] = 0;
+        if (threadIdx.x < 3) group_ticks[threadIdx.x] = 0;
+    }
+    const bool timed = STATS && (blockIdx.x & 63u) == 0u;
     int cur = 0;
     for (int round = 0; ; round++) {
         if (gq.n_ext[cur] == 0) break;                          // every pixel of the group is written
         if (round >= w.round_limit) { if (threadIdx.x == 0) *w.lost = 1; break; }
-        extend_stage<F, W>(sv, ra, w, out, my_stack, faces, gq, cur, first);
+        if (timed && threadIdx.x == 0) group_ticks[2] = clock64();
+        extend_stage<F, W, STATS>(sv, ra, w, out, my_stack, faces, gq, cur, first, group_stats);
         __syncthreads();                                        // the material queues are complete
-        for (int q = 0; q < NQ; q++) shade_stage<F, W>(sv, ra, w, q, out, faces, gq, cur, first);
+        if (timed && threadIdx.x == 0) { const unsigned long long now = clock64(); group_ticks[0] += now - group_ticks[2]; group_ticks[2] = now; }
+        for (int q = 0; q < NQ; q++) shade_stage<F, W, STATS>(sv, ra, w, q, out, faces, gq, cur, first, group_stats);
         __syncthreads();                                        // the next extend queue is complete; everyone has read this round's counts
-        if (threadIdx.x == 0) gq.n_ext[cur] = 0;
+        if (threadIdx.x == 0) {
+            if (timed) group_ticks[1] += clock64() - group_ticks[2];
+            gq.n_ext[cur] = 0;
+        }
         if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
         cur ^= 1;
         __syncthreads();
+    }
+    if constexpr (STATS) {
+        if (threadIdx.x == 0) {
+            atomicAdd(&w.stats[0], 1ull);
+            for (int k = 1; k < 12; k++) if (group_stats[k]) atomicAdd(&w.stats[k], (unsigned long long)group_stats[k]);
+            if (timed) { atomicAdd(&w.stats[12], group_ticks[0]); atomicAdd(&w.stats[13], group_ticks[1]); atomicAdd(&w.stats[14], 1ull); }
+        }
     }
 }
 
@@ -349,7 +380,8 @@ bool hip_ok2(hipError_t e, const char* what)
 template <uint32_t F, class W>
 void launch_groups(const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned groups, float* out, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_wf_groups<F, W>), dim3(groups), dim3(256), 0, st, sv, ra, w, out);
+    if (ra.stage_stats) hipLaunchKernelGGL((k_wf_groups<F, W, true>), dim3(groups), dim3(256), 0, st, sv, ra, w, out);
+    else hipLaunchKernelGGL((k_wf_groups<F, W, false>), dim3(groups), dim3(256), 0, st, sv, ra, w, out);
 }
 
 // The feature mask of the kernel a scene variant runs on (what launch_variant instantiates): it,
@@ -441,23 +473,27 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
         w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_lanes * 4));
     }
     w.lost = reinterpret_cast<int*>(take(256));
+    w.stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.lost) + 64);
+    static_assert(sizeof(PtStageStats) == 16 * sizeof(unsigned long long) && 64 + sizeof(PtStageStats) <= 256, "the flag block holds the stage counters");
     w.group_lanes = group_lanes;
     // a round is one bounce of every live lane of the group, and a pixel is at most ns paths of
     // max_depth bounces plus the round that ends each: more rounds than that mean a lane was lost
     const long long limit = (long long)ra.ns * ((long long)ra.max_depth + 2) + 8;
     w.round_limit = (int32_t)std::min<long long>(limit, 0x7fffffff);
-    if (!hip_ok2(hipMemsetAsync(w.lost, 0, sizeof(int), st), "hipMemsetAsync(flag)")) return PT_ERR_HIP;
+    if (!hip_ok2(hipMemsetAsync(w.lost, 0, 256, st), "hipMemsetAsync(flag and stage counters)")) return PT_ERR_HIP;
 
     launch_variant(sc->variant, sc->view, ra, w, groups, d_out, st);
     if (!hip_ok2(hipGetLastError(), "wavefront launch")) return PT_ERR_HIP;
     int lost = 0;
     if (!hip_ok2(hipMemcpyAsync(&lost, w.lost, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(flag)")) return PT_ERR_HIP;
+    if (ra.stage_stats && !hip_ok2(hipMemcpyAsync(&sc->stage_stats, w.stats, sizeof(PtStageStats), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(stage counters)")) return PT_ERR_HIP;
     if (!hip_ok2(hipStreamSynchronize(st), "wavefront render")) return PT_ERR_HIP;
     if (lost) {
         pt::set_error("wavefront: a group did not finish within the rounds its sample and bounce counts allow");
         return PT_ERR_HIP;
     }
     sc->last.n_launches = 1;
+    if (ra.stage_stats) sc->have_stage_stats = true;
     return PT_OK;
 }
 

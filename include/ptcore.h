@@ -232,7 +232,9 @@ typedef struct PtRenderParams {
     int32_t batch_index, batch_count;
     int32_t raw_sum;
     int32_t chunk_samples; /* PT_SCHEDULE_CHUNKS, _REFILL, _WALK (and what AUTO picks): samples per chunk; 0 = the library's choice */
-    int32_t reserved[2];
+    int32_t stage_stats;   /* PT_PIPELINE_WAVEFRONT: != 0 counts what the stages did, for pt_render_stage_stats (a kernel of
+                            * its own: the counting costs the rectangle scene's staged render about 6 % of its rate)      */
+    int32_t reserved;
 } PtRenderParams;
 
 /* One ray for pt_trace_closest.  The hit range is the integrator's [0.001, FLT_MAX]
@@ -263,6 +265,25 @@ typedef struct PtRenderStats {
     int32_t  n_chunks;       /* chunks every pixel's samples were cut into (CHUNKS, or REFILL / WALK on a large shard); 0 = not cut */
     uint64_t reserved[2];
 } PtRenderStats;
+
+/* What the stages of the staged pipeline (PT_PIPELINE_WAVEFRONT) did in the most recent render: the reference has
+ * one thread per pixel and nothing to report (its only counter is finished pixels, src/ptMain.cu:186-188).  A
+ * group is the 256 or 512 pixel lanes one workgroup owns; a round is one pass of its extend stage (closest hit for
+ * every queued ray) and of its shade stage (one queue per material kind).  Queue occupancy of a stage is
+ * lanes / (64 * waves): the share of lanes that had an entry in the waves the stage ran.  Time share of a stage is
+ * its ticks over the sum of both, times PtRenderStats.kernel_ms. */
+typedef struct PtStageStats {
+    uint64_t groups;          /* workgroups of the launch                                                     */
+    uint64_t rounds;          /* rounds, summed over groups                                                   */
+    uint64_t extend_lanes;    /* rays searched                                                                */
+    uint64_t extend_waves;    /* waves the extend stage ran: 64 queue entries each, a round's last one partly filled */
+    uint64_t shade_lanes[4];  /* hits shaded from the Lambertian, Metal, Dielectric and Isotropic queue       */
+    uint64_t shade_waves[4];
+    uint64_t extend_ticks;    /* shader-clock ticks between a round's start and the barrier after its searches, summed over the timed groups */
+    uint64_t shade_ticks;     /* ... and from there to the barrier after its shading                          */
+    uint64_t timed_groups;    /* groups that read the clock: one in 64 (reading it every round costs the others too much) */
+    uint64_t reserved;
+} PtStageStats;
 
 typedef struct PtScene PtScene;
 
@@ -323,6 +344,10 @@ int  pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, int32_t* prim
 
 /* Fills *stats with the timings of the scene's most recent render call; waits for it. */
 int  pt_render_stats(PtScene* scene, PtRenderStats* stats);
+
+/* Counters of the most recent render on this scene that ran on the staged pipeline with PtRenderParams.stage_stats
+ * set (PT_ERR_INVALID when none has). */
+int  pt_render_stage_stats(PtScene* scene, PtStageStats* stats);
 
 /* One call, several GPUs of this process: the scene is created on every device of device_ids,
  * each traces the 8x8-tile shard (shard_index = its position in device_ids) concurrently, and the

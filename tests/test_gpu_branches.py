@@ -235,3 +235,39 @@ def test_two_million_triangles_at_full_scale(oracle):
     for s in range(8):
         acc += sc.render(nx, ny, 1, shard_index=s, shard_count=8)
     assert_bit_exact(acc, a, "8 shards")
+
+
+def test_staged_pipeline_reports_what_its_stages_did(oracle):
+    """pt_render_stage_stats after a render on the staged pipeline: the rays its extend stage searched and the hits
+    its material queues shaded are the counting oracle's closest-hit searches and scatters for the same frame,
+    queue occupancy and the stages' time shares are fractions, and the fused pipeline leaves the counters alone."""
+    from tests import _oracle_stats
+    d = pt.builtin_scene("cornell", 96 / 64)
+    sc = pt.Scene(d)
+    with pytest.raises(pt.PtError):
+        sc.stage_stats()                                            # nothing has run on the staged pipeline yet
+    img = sc.render(96, 64, 6, pipeline=abi.PIPELINE_WAVEFRONT)
+    with pytest.raises(pt.PtError):
+        sc.stage_stats()                                            # ... with the counters asked for
+    assert np.array_equal(sc.render(96, 64, 6, pipeline=abi.PIPELINE_WAVEFRONT, stage_stats=1).view(np.uint32), img.view(np.uint32))
+    st = sc.stage_stats()
+    cnt, ref = _oracle_stats.counters(d, 96, 64, 6)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert st["groups"] == (96 // 8) * (64 // 8) * 64 // 256
+    assert st["extend_lanes"] == cnt["world_hits"]
+    assert st["shade_lanes"] == [cnt["diffuse_scatters"], 0, 0, 0]   # a Cornell box is Lambertian walls and a lamp (which ends a path in the extend stage)
+    assert st["rounds"] >= st["groups"] and st["extend_waves"] >= st["rounds"]
+    assert 0.3 < st["extend_occupancy"] <= 1.0 and 0.2 < st["shade_occupancy"] <= 1.0
+    assert 0.05 < st["extend_time_share"] < 0.95
+    sc.render(96, 64, 2)                                            # the fused pipeline, and a staged render that does not count:
+    sc.render(96, 64, 2, pipeline=abi.PIPELINE_WAVEFRONT)           # the counters stay what they were
+    assert sc.stage_stats() == st
+    # every material queue of the sphere scene fills: Lambertian, metal, glass
+    d2 = pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)
+    sc2 = pt.Scene(d2)
+    sc2.render(160, 80, 4, pipeline=abi.PIPELINE_WAVEFRONT, stage_stats=1)
+    st2 = sc2.stage_stats()
+    cnt2, _ = _oracle_stats.counters(d2, 160, 80, 4)
+    assert st2["extend_lanes"] == cnt2["world_hits"]
+    assert all(n > 0 for n in st2["shade_lanes"][:3]) and st2["shade_lanes"][3] == 0
+    assert sum(st2["shade_lanes"]) <= st2["extend_lanes"]
