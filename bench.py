@@ -33,7 +33,7 @@ with open(os.path.join(ROOT, "bench", "work_model.json")) as _f:
     FLOP_PER_PATH = {k: v["flop_per_path"] for k, v in json.load(_f)["configs"].items()}
 # HBM bytes one launch moves, from the committed rocprofv3 PMC pass (FETCH_SIZE + WRITE_SIZE with
 # the guide's unit and gfx950 corrections): the frame is written once, the scene stays in cache.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_cornell1024x4096_k_render_chunks.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_cornell1024x4096_k_render_chunks.json")
 # fp32 vector peak without FMA: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (with FMA: 157.3 TFLOP/s).  Measured
 # (tools/valu_probe.hip): plain add/mul/fma on vector registers issue at that rate; compares, selects,
 # min/max, integer multiplies, fp64, conversions and the scale / fix-up steps of a divide at half of it.
@@ -62,10 +62,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-staged", action="store_true", help="skip the one render on the staged (wavefront) pipeline reported beside the headline")
     ap.add_argument("--frame-hash", action="store_true", help="add the SHA-1 of the final frame on rank 0 to the result line")
-    ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles",
+    ap.add_argument("--shard", choices=("tiles", "samples", "hybrid"), default="tiles",
                     help="tiles: whole pixels per rank, the reference's image bit for bit (default).  samples: every rank "
                          "traces spp/N samples of every pixel from its own seeds -- not the reference's random sequence, "
-                         "equal to it up to sampling noise")
+                         "equal to it up to sampling noise.  hybrid: --tile-shards T tile shards x N/T sample batches, "
+                         "the smallest departure from the reference's sequence that keeps every GPU busy")
+    ap.add_argument("--tile-shards", type=int, default=2, help="tile shards of the hybrid sharding (the ranks divide into that many)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,13 +114,24 @@ def main():
 
     kernel_ms = []
 
-    by_samples = args.shard == "samples" and world > 1
-    if world > 1 and args.spp % world and by_samples:
+    # how the ranks divide the frame: (tile shards, sample batches).  (N, 1) is the reference's image bit for bit.
+    T = args.tile_shards
+    hybrid_ok = world >= 4 and T >= 2 and world % T == 0 and world // T >= 2 and args.spp % (world // T) == 0
+    samples_ok = world > 1 and args.spp % world == 0
+    mode = args.shard if world > 1 else "tiles"
+    if mode == "samples" and not samples_ok:
         raise SystemExit("bench.py: --shard samples needs spp divisible by the number of GPUs")
+    if mode == "hybrid" and not hybrid_ok:
+        raise SystemExit("bench.py: --shard hybrid needs at least 4 GPUs, divisible by --tile-shards, and spp divisible by the batches")
+    by_samples = mode != "tiles"
+    split = {"tiles": (world, 1), "samples": (1, world), "hybrid": (T, max(1, world // T))}
 
     def step(record, samples):
-        if samples:           # raw sums of this rank's batch; added by the reduce, averaged + gamma'd once on the root
-            scene.render_device(frame.ptr, nx, ny, args.spp // world, args.depth, batch_index=rank, batch_count=world, raw_sum=1)
+        """samples: False, or the name of a sharding that divides a pixel's samples ("samples", "hybrid")."""
+        if samples:           # raw sums of this rank's batch of its tile shard; added by the reduce, averaged + gamma'd once on the root
+            tiles, batches = split[samples]
+            scene.render_device(frame.ptr, nx, ny, args.spp // batches, args.depth, shard_index=rank % tiles, shard_count=tiles, tile=(8, 8),
+                                batch_index=rank // tiles, batch_count=batches, raw_sum=1)
         else:
             scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, shard_index=rank, shard_count=world, tile=(8, 8))
         if record:
@@ -156,7 +169,7 @@ def main():
             dt = group.allreduce_max(dt)
         return dt
 
-    dt = timed(by_samples, True)
+    dt = timed(mode if by_samples else False, True)
     fused_stats = scene.stats()              # of the headline's last launch, before anything else renders
     frame_sha1 = None
     if args.frame_hash and rank == 0:       # the headline's frame, before the second sharding below overwrites it
@@ -165,9 +178,41 @@ def main():
     # Beside the headline (tile shards: the reference's image bit for bit), the same frame with the
     # samples of every pixel split over the ranks: the other sharding the task names, equal to the
     # reference's image up to sampling noise only.  Reported, never used for `value`.
-    dt_samples = None
-    if world > 1 and not by_samples and args.spp % world == 0:
-        dt_samples = timed(True, False)
+    dt_samples = dt_hybrid = None
+    noise = None
+    if world > 1 and not by_samples:
+        one_stream = frame.to_host().reshape(ny, nx, 3).copy() if rank == 0 else None
+        batch_frames = {}
+        if samples_ok:
+            dt_samples = timed("samples", False)
+            if rank == 0:
+                batch_frames["samples"] = frame.to_host().reshape(ny, nx, 3).copy()
+        if hybrid_ok:
+            dt_hybrid = timed("hybrid", False)
+            if rank == 0:
+                batch_frames["hybrid"] = frame.to_host().reshape(ny, nx, 3).copy()
+        if batch_frames or samples_ok or hybrid_ok:
+            # The tolerance the batched frames are held to: per channel, their RMSE against the one-stream frame within
+            # 1.5 x the RMSE of two one-stream frames from disjoint seeds (two independent estimates of the same pixels,
+            # sqrt(2) sigma apart however the samples were drawn).  The second one-stream frame: every pixel seeded with
+            # i + nx*ny instead of i, tile-sharded like the headline.
+            scene.render_device(frame.ptr, nx, ny, args.spp, args.depth, shard_index=rank, shard_count=world, tile=(8, 8), batch_index=1, batch_count=2)
+            if comm is not None:
+                comm.reduce_frame(frame.ptr, n_floats, root=0)
+            else:
+                total = group.reduce_sum(frame.to_host(), root=0)
+                if rank == 0:
+                    frame.from_host(total)
+            pt.synchronize()
+            if rank == 0:
+                other = frame.to_host().reshape(ny, nx, 3)
+                rmse = lambda a, b: np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean(axis=(0, 1)))
+                floor = rmse(one_stream, other)
+                noise = {"rmse_two_one_stream_frames_rgb": [float(v) for v in floor], "tolerance": "RMSE(batched, one-stream) <= 1.5 x that, per channel"}
+                for k, f in batch_frames.items():
+                    r = rmse(f, one_stream)
+                    noise[k] = {"rmse_vs_one_stream_rgb": [float(v) for v in r], "ratio_rgb": [float(v) for v in r / np.maximum(floor, 1e-30)],
+                                "within_tolerance": bool((r <= 1.5 * floor).all())}
 
     # Beside the headline (the fused pipeline), one render of the same frame on the staged pipeline
     # (generate / extend / shade by material queue / accumulate, pt_wavefront.hip): its rate and whether
@@ -182,6 +227,17 @@ def main():
         staged = {"value": st.paths / st.kernel_ms / 1e3, "unit": "Mpaths/s", "kernel_ms": st.kernel_ms, "launches": st.n_launches,
                   "frame_equals_fused_bit_for_bit": bool(np.array_equal(frame.to_host().view(np.uint32), fused_frame.view(np.uint32))),
                   "note": "PT_PIPELINE_WAVEFRONT, one launch of k_wf_groups; not part of `value`"}
+        # what its stages did, from the counting form of the same kernel (an eighth of the samples: the counters cost it 6 %)
+        scene.render_device(frame.ptr, nx, ny, max(1, args.spp // 8), args.depth, pipeline=abi.PIPELINE_WAVEFRONT, stage_stats=1)
+        pt.synchronize()
+        ss, k_ms = scene.stage_stats(), scene.stats().kernel_ms
+        staged["stages"] = {"spp": max(1, args.spp // 8), "kernel_ms": k_ms, "groups": ss["groups"], "rounds_per_group": ss["rounds"] / max(1, ss["groups"]),
+                            "extend": {"lanes": ss["extend_lanes"], "queue_occupancy": ss["extend_occupancy"], "time_share": ss["extend_time_share"],
+                                       "ms": k_ms * ss["extend_time_share"]},
+                            "shade": {"lanes_by_queue": dict(zip(("lambertian", "metal", "dielectric", "isotropic"), ss["shade_lanes"])),
+                                      "queue_occupancy": ss["shade_occupancy"], "time_share": 1.0 - ss["extend_time_share"],
+                                      "ms": k_ms * (1.0 - ss["extend_time_share"])},
+                            "note": "pt_render_stage_stats; occupancy = queue entries / (64 x waves run); time shares from the shader clock in one group of 64"}
 
     paths_per_step = nx * ny * args.spp
     value = paths_per_step * args.steps / dt / 1e6
@@ -235,7 +291,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s_box %dx%d %dspp depth%d (BASELINE configs[2])" % (args.scene, nx, ny, args.spp, args.depth)
                        if args.scene == "cornell" else "%s %dx%d %dspp depth%d" % (args.scene, nx, ny, args.spp, args.depth),
-                       "sharding": ("sample batches per rank (own seeds: not the reference's sequence)" if by_samples
+                       "sharding": ("%d tile shards x %d sample batches (own seeds per batch: not the reference's sequence)" % split[mode] if by_samples
                                     else "8x8 pixel tiles round-robin over ranks"),
                        "pipeline": "fused", "collective": collective},
             "roofline": roofline, "cpu_baseline": cpu,
@@ -250,7 +306,15 @@ def main():
             result["sample_batch_sharding"] = {
                 "value": paths_per_step * args.steps / dt_samples / 1e6, "unit": "Mpaths/s", "ms_per_step": dt_samples / args.steps * 1e3,
                 "note": "every rank traces spp/N samples of every pixel from its own seeds, raw sums reduced, finished on rank 0; "
-                        "not the reference's random sequence (PSNR-tested), not part of `value`"}
+                        "not the reference's random sequence (equal to it within the stated RMSE tolerance), not part of `value`"}
+        if dt_hybrid is not None:
+            result["hybrid_sharding"] = {
+                "value": paths_per_step * args.steps / dt_hybrid / 1e6, "unit": "Mpaths/s", "ms_per_step": dt_hybrid / args.steps * 1e3,
+                "tile_shards": split["hybrid"][0], "sample_batches": split["hybrid"][1],
+                "note": "rank r traces tile shard r % T of sample batch r // T; batch 0 is the reference's stream, the others their own "
+                        "seeds; not part of `value`"}
+        if noise is not None:
+            result["batched_frames_vs_sampling_noise"] = noise
     hip_libs, _ = hostgroup.mapped_runtimes()
     barrier()
     if comm is not None:

@@ -37,13 +37,18 @@ def main():
             sys.exit(1)            # start nothing more after a failed GPU step
         per = {}
         disp = set()
+        spans = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if needle not in row["Kernel_Name"]:
                     continue
                 per[row["Counter_Name"]] = per.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                 disp.add(row["Dispatch_Id"])
+                if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                    spans[row["Dispatch_Id"]] = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6
         launches = max(launches, len(disp))
+        if spans and "FETCH_SIZE" in group:      # the kernel's time in the very pass that counted its bytes: bytes / time = GB/s as measured
+            sums["_kernel_ms_sum_in_fetch_pass"] = sum(spans.values())
         sums.update(per)
         print("pass %d ok: %s" % (i, sorted(per)), flush=True)
     s = sums
@@ -65,6 +70,8 @@ def main():
         der["fetch_bytes_per_launch_corrected_x2"] = s["FETCH_SIZE"] * 1024.0 * 2.0 / max(1, launches)
     if "WRITE_SIZE" in s:
         der["write_kib_per_launch"] = s["WRITE_SIZE"] / max(1, launches)
+    if s.get("_kernel_ms_sum_in_fetch_pass"):
+        der["kernel_ms_avg"] = s["_kernel_ms_sum_in_fetch_pass"] / max(1, launches)
     s["_derived"] = der
     # which build was profiled: bench.py only quotes these numbers for the library they were measured on
     import hashlib
