@@ -9,6 +9,7 @@
 //     (src/ptMain.cu:153-169), which is what makes images comparable sample for sample.
 //   * k_trace_closest: world->hit for a batch of rays (closest-hit parity entry point).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdio>
@@ -763,8 +764,13 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // less than two rounds stay with TILES; RTNW final through the 4-wide tree 1920x1080 x256 205.3 / 192.1; seven
     // spheres in the room (list walk) 1024^2 x1024 302.9 / 325.4: its chunk kernel compiles 10 % slower, so it stays too.
     ra.chunk_samples = ra.n_chunks = 0;
+    // With the later chunks of expensive tiles at a raised wave priority (k_render_chunks) the chunks also pay on shards
+    // of two thirds of a round and more once a pixel has a thousand samples -- what two to four GPUs hold of the
+    // headline frame (kernel ms, TILES / CHUNKS without / with the priority): x4096 whole frame 241 / 212.3 / 208.4, half
+    // 138.9 / 134.1 / 134.3, a quarter 93.9 / 102.2 / 83.2, an eighth 69.1 / 85.2 / 78.1 (stays with TILES); x1024 a third
+    // 28.1 / - / 25.6, a quarter 24.3 / - / 22.4, a sixth 20.6 / - / 21.0; x512 half 18.2 / - / 19.4, a quarter 12.5 / - / 12.5.
     const bool chunks_pay = (sc->variant == V_CORNELL_WORLD || sc->variant == V_FINAL_LBVH4 || sc->variant == V_FINAL_LBVH) &&
-                            ra.n_wave_tiles >= 2 * CHUNK_WAVE_SLOTS;
+                            (ra.n_wave_tiles >= 2 * CHUNK_WAVE_SLOTS || (3 * ra.n_wave_tiles >= 2 * CHUNK_WAVE_SLOTS && p->ns >= 1024));
     if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill == 0 && ra.n_wave_tiles > 0 && !no_alloc &&
         (p->schedule == PT_SCHEDULE_CHUNKS || (p->schedule == PT_SCHEDULE_AUTO && chunks_pay))) {
         int chunk = p->chunk_samples;
@@ -810,6 +816,10 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
             if (ra.n_chunks < 2) ra.chunk_samples = ra.n_chunks = 0;
         }
     }
+    ra.chunk_priority = 1;
+#ifdef PT_EXP_ENV                       // kernel experiments
+    if (getenv("PT_CHUNK_PRIORITY")) ra.chunk_priority = atoi(getenv("PT_CHUNK_PRIORITY"));
+#endif
     ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
@@ -868,7 +878,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         } else if (ra.n_chunks > 0) {
             const size_t groups = (size_t)ra.n_wave_tiles;          // progress words: one per work item group, at most one per wave tile
             const size_t states_bytes = ((size_t)p->nx * (size_t)p->ny * sizeof(unsigned long long) + 255) & ~(size_t)255;
-            const size_t words_bytes = (1 + groups) * sizeof(unsigned);
+            const size_t words_bytes = (4 + 2 * groups) * sizeof(unsigned);      // ticket, cost sum and count, a progress and a cost word per group
             if (sc->chunk_workspace_bytes < states_bytes + words_bytes) {
                 if (sc->chunk_workspace) { (void)hipFree(sc->chunk_workspace); sc->chunk_workspace = nullptr; sc->chunk_workspace_bytes = 0; }
                 if (hipMalloc(&sc->chunk_workspace, states_bytes + words_bytes) != hipSuccess) {

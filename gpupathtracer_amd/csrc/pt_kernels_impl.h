@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? CHUNK_WAVES * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[FaceTable<F, W>::float4s];
-    __shared__ unsigned s_item;
+    __shared__ unsigned s_item, s_prio;
     face_table_to_lds<F, W>(sv, faces);
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
@@ -257,7 +257,16 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
     const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
     const unsigned groups = (unsigned)(ra.n_wave_tiles + CHUNK_WAVES - 1) / (unsigned)CHUNK_WAVES;
     const unsigned n_items = groups * (unsigned)ra.n_chunks;
-    unsigned* const progress = words + 1;
+    // words: [0] the ticket, [1] [2] sum and count of the groups' first-chunk costs, [4 ..) a progress word per group,
+    // then a cost word per group.  A launch cannot end before its most expensive tile has run through all its chunks,
+    // one after the other, and among six waves on a SIMD that chain advances at a sixth of the pace it has alone
+    // (tiles differ by a factor of five in bounces per pixel).  So a group's first chunk is timed, and its later chunks
+    // run at a wave priority that grows with that time over the mean's: the expensive chains are served first by
+    // their SIMDs and the cheap tiles fill what is left.  Which wave issues first changes no value.
+    unsigned* const progress = words + 4;
+    unsigned* const cost = words + 4 + groups;
+    unsigned long long item_began = 0;
+    unsigned finished_cost = 0;
     // Thread 0 has one errand per round, between the barrier that ends an item and the one that starts the next:
     // publish the finished item, then draw the next number.  (Written as two -- one at the end of the loop body,
     // one at its start -- the compiler joins them across the loop's back edge into a loop of thread 0's own and
@@ -266,7 +275,14 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
     unsigned finished_grp = 0, finished_c = 0;
     while (true) {
         if (threadIdx.x == 0) {
-            if (finished_one) __hip_atomic_store(&progress[finished_grp], finished_c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (finished_one) {
+                if (finished_c == 0 && ra.chunk_priority) {
+                    __hip_atomic_store(&cost[finished_grp], finished_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&words[1], finished_cost); atomicAdd(&words[2], 1u);
+                }
+                __hip_atomic_store(&progress[finished_grp], finished_c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_prio = 0;
             s_item = atomicAdd(&words[0], 1u);
         }
         __syncthreads();
@@ -291,10 +307,25 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
                     __builtin_amdgcn_s_sleep(64);
                     if (++spins > (1u << 23)) { *fault = 2; break; }
                 }
+                if (ra.chunk_priority) {                      // this group's first chunk against the mean of those finished so far
+                    const unsigned long long mine = __hip_atomic_load(&cost[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long sum = __hip_atomic_load(&words[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long cnt = __hip_atomic_load(&words[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long tenths = sum ? 10ull * mine * cnt / sum : 10ull;
+                    s_prio = tenths >= 15 ? 3u : tenths >= 12 ? 2u : tenths >= 9 ? 1u : 0u;
+                }
             }
             __syncthreads();
             __threadfence();                                  // every wave: the loads below come after the word
         }
+        {
+            const unsigned prio = (unsigned)__builtin_amdgcn_readfirstlane((int)s_prio);
+            if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+            else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+            else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        item_began = clock64();
         const int wave = (int)grp * CHUNK_WAVES + wave_in_block;
         int x = 0, ytop = 0;
         if (wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop)) {
@@ -319,6 +350,7 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
         __threadfence();                                      // every lane's stores before the word
         __syncthreads();                                      // (also: everyone has read s_item)
         finished_one = true; finished_grp = grp; finished_c = (unsigned)c;
+        finished_cost = (unsigned)min((unsigned long long)0xffffffffu, (clock64() - item_began) >> 6);
     }
 }
 

@@ -36,3 +36,42 @@ def test_chunk_kernels_keep_ticket_and_barriers_in_one_loop(tmp_path):
     for unit in units:
         ok = [l for l in r.stdout.splitlines() if l.startswith("ok") and (" " + unit + ".hip.s ") in l.replace("  ", " ")]
         assert len(ok) == EXPECTED.get(unit, 1), "%s: %d\n%s" % (unit, len(ok), r.stdout)
+
+
+def test_the_loop_check_tells_a_stray_barrier_loop_from_block_placement(tmp_path):
+    """The checker itself, on hand-written assembly: (a) the sound shape -- ticket and barriers in one loop, with a cold
+    block laid out behind the loop that jumps back into its body (a backward branch that is no loop); (b) the shape
+    that hangs -- an inner loop around the barriers that the ticket draw is not part of."""
+    head = "_Z15k_render_chunksILj1EEvv:\n\ts_mov_b32 s0, 0\n"
+    good = head + """.LBB0_1:
+\tglobal_atomic_add v1, v0, v1, s[2:3] sc0
+\ts_barrier
+\ts_cbranch_scc1 .LBB0_9
+.LBB0_2:
+\tv_mov_b32 v0, v1
+\ts_barrier
+\ts_cbranch_scc0 .LBB0_1
+\ts_branch .LBB0_10
+.LBB0_9:
+\tv_mov_b32 v2, v1
+\ts_branch .LBB0_2
+.LBB0_10:
+\ts_endpgm
+"""
+    bad = head + """.LBB0_1:
+\tglobal_atomic_add v1, v0, v1, s[2:3] sc0
+.LBB0_2:
+\ts_barrier
+\tv_mov_b32 v0, v1
+\ts_barrier
+\ts_cbranch_scc0 .LBB0_2
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+"""
+    for name, text, want in (("good", good, 0), ("bad", bad, 1)):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "k.s").write_text(text)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_chunk_kernel_loops.py"), str(d)], capture_output=True, text=True)
+        assert r.returncode == want, r.stdout + r.stderr
+        assert ("BAD" in r.stdout) == bool(want)
