@@ -3,7 +3,7 @@
 # into profiles/<round>/ afterwards):  tools/collect_profiles.sh r02
 # Every GPU step runs under its own time limit; the script stops at the first failure.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 T="timeout -k 10"
