@@ -85,10 +85,10 @@ void launch_render(int variant, const SceneView& sv, const RenderArgs& ra, float
 #undef PT_LAUNCH
 }
 
-void launch_chunks(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault,
+void launch_chunks(int variant, const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* tile_states, int* fault,
                    hipStream_t st)
 {
-#define PT_LAUNCH(F, W) FusedLaunch<F, W>::chunks(sv, ra, out, words, rng_states, fault, st)
+#define PT_LAUNCH(F, W) FusedLaunch<F, W>::chunks(sv, ra, out, words, tile_states, fault, st)
     PT_FOR_VARIANT(variant, PT_LAUNCH)
 #undef PT_LAUNCH
 }
@@ -877,7 +877,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
             launch_render(launch_variant(sc, ra), sc->view, ra, out, slot_counter, static_cast<unsigned long long*>(sc->chunk_workspace), sc->bad_resume_dev, st);
         } else if (ra.n_chunks > 0) {
             const size_t groups = (size_t)ra.n_wave_tiles;          // progress words: one per work item group, at most one per wave tile
-            const size_t states_bytes = ((size_t)p->nx * (size_t)p->ny * sizeof(unsigned long long) + 255) & ~(size_t)255;
+            const size_t states_bytes = (size_t)ra.n_wave_tiles * 1280;         // CHUNK_TILE_STATE_WORDS 64-bit words per wave tile
             const size_t words_bytes = (4 + 2 * groups) * sizeof(unsigned);      // ticket, cost sum and count; a progress and a cost word per group
             if (sc->chunk_workspace_bytes < states_bytes + words_bytes) {
                 if (sc->chunk_workspace) { (void)hipFree(sc->chunk_workspace); sc->chunk_workspace = nullptr; sc->chunk_workspace_bytes = 0; }

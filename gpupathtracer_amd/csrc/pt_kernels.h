@@ -19,7 +19,7 @@ struct FusedLaunch {
     static void render(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* next_slot, unsigned long long* chunk_rec, int* fault,
                        hipStream_t st);
     // words: [0] the ticket counter, [1 ..] one progress word per group of four wave tiles, all zero at launch
-    static void chunks(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault, hipStream_t st);
+    static void chunks(const ptd::SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* tile_states, int* fault, hipStream_t st);
     static void pass(const ptd::SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume, hipStream_t st);
     static void trace(const ptd::SceneView& sv, const PtRay* rays, size_t n, int32_t* ids, float* ts, hipStream_t st);
 };

@@ -230,9 +230,10 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
 // slots), the launch ends with most of the GPU idle behind its last items, and the same paths traced as a
 // 4096^2 frame at 256 samples take 16 % less time.  Here the work item is (chunk, group of four wave tiles),
 // numbered chunk-major; persistent workgroups draw item numbers from a counter, so items start in order.
-// A pixel's samples stay one sequence (src/ptMain.cu:156-162): its random stream's state waits in `rng_states`
-// and its running sum in the frame itself between chunks, and chunk c of a group starts once the group's
-// progress word says chunk c - 1 has been stored.  That wait cannot deadlock: the item waited for has a
+// A pixel's samples stay one sequence (src/ptMain.cu:156-162): between chunks its random stream's state and its
+// running sum wait in `tile_states`, 1280 bytes per wave tile (64 states of 8 bytes, then the sum's three components as
+// three rows of 64 floats), so that a wave stores and loads whole 128-byte lines whatever the tile's place in the frame;
+// chunk c of a group starts once the group's progress word says chunk c - 1 has been stored.  That wait cannot deadlock: the item waited for has a
 // smaller number, so a running workgroup holds it, and the chain of waits ends at a chunk 0, which waits for
 // nothing.  The wait is bounded all the same; running out raises *fault (the frame is then wrong, and the
 // host says so).
@@ -242,9 +243,10 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_pass(SceneV
 // wave tiles per work item = waves per workgroup.  4 / 2 / 1 (-DPT_CHUNK_WAVES): rectangle scene 1024^2 x4096 213.2 / 216.5 / 211.8 ms,
 // RTNW final through the 4-wide tree 1920x1080 x256 192.0 / 190.9 / 187.0: the waves of a workgroup waiting for each other is not what is left
 constexpr int CHUNK_WAVES = PT_CHUNK_WAVES;
+constexpr int CHUNK_TILE_STATE_WORDS = 64 + 3 * 32;      // 64-bit words of a wave tile's state between chunks: 1280 bytes
 template <uint32_t F, class W>
 __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_render_chunks(SceneView sv, RenderArgs ra, float* __restrict__ out,
-                                                                             unsigned* __restrict__ words, unsigned long long* __restrict__ rng_states,
+                                                                             unsigned* __restrict__ words, unsigned long long* __restrict__ tile_states,
                                                                              int* __restrict__ fault)
 {
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? CHUNK_WAVES * 64 * LBVH_LDS_STACK : 1];
@@ -333,9 +335,11 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
             lane_init(st);
             unsigned i;
             lane_begin_pixel(st, ra, x, ytop, i);
+            unsigned long long* const tile_rng = tile_states + (size_t)wave * CHUNK_TILE_STATE_WORDS;
+            float* const tile_sum = reinterpret_cast<float*>(tile_rng + 64);
             if (c > 0) {
-                st.rng.state = rng_states[i];
-                st.accum = mk(out[3 * (size_t)i + 0], out[3 * (size_t)i + 1], out[3 * (size_t)i + 2]);
+                st.rng.state = tile_rng[lane];
+                st.accum = mk(tile_sum[lane], tile_sum[64 + lane], tile_sum[128 + lane]);
                 st.s = c * ra.chunk_samples;
             }
             const int ns_end = min(ra.ns, (c + 1) * ra.chunk_samples);     // this item's samples end where the next chunk begins
@@ -343,8 +347,8 @@ __global__ __launch_bounds__(64 * CHUNK_WAVES, fused_min_blocks(F)) void k_rende
             if (c == ra.n_chunks - 1) {
                 lane_write_pixel(st, ra, i, out);
             } else {
-                rng_states[i] = st.rng.state;
-                out[3 * (size_t)i + 0] = st.accum.x; out[3 * (size_t)i + 1] = st.accum.y; out[3 * (size_t)i + 2] = st.accum.z;
+                tile_rng[lane] = st.rng.state;
+                tile_sum[lane] = st.accum.x; tile_sum[64 + lane] = st.accum.y; tile_sum[128 + lane] = st.accum.z;
             }
         }
         __threadfence();                                      // every lane's stores before the word
@@ -673,11 +677,11 @@ void FusedLaunch<F, W>::render(const SceneView& sv, const RenderArgs& ra, float*
     else hipLaunchKernelGGL((k_render_tiles<F, W>), grid, block, 0, st, sv, ra, out);
 }
 template <uint32_t F, class W>
-void FusedLaunch<F, W>::chunks(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* rng_states, int* fault, hipStream_t st)
+void FusedLaunch<F, W>::chunks(const SceneView& sv, const RenderArgs& ra, float* out, unsigned* words, unsigned long long* tile_states, int* fault, hipStream_t st)
 {
     const long long items = (long long)((ra.n_wave_tiles + CHUNK_WAVES - 1) / CHUNK_WAVES) * ra.n_chunks;
     const dim3 block(64 * CHUNK_WAVES), grid((unsigned)std::min<long long>(items, 8192 / CHUNK_WAVES));     // persistent: 256 CUs hold at most 24 waves each
-    hipLaunchKernelGGL((k_render_chunks<F, W>), grid, block, 0, st, sv, ra, out, words, rng_states, fault);
+    hipLaunchKernelGGL((k_render_chunks<F, W>), grid, block, 0, st, sv, ra, out, words, tile_states, fault);
 }
 template <uint32_t F, class W>
 void FusedLaunch<F, W>::pass(const SceneView& sv, const RenderArgs& ra, PtAccumPixel* acc, int first, float* out, int* bad_resume, hipStream_t st)
