@@ -465,17 +465,17 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     PtScene* sc = new PtScene();
     if (!hip_ok(hipGetDevice(&sc->device), "hipGetDevice")) { delete sc; return PT_ERR_HIP; }
     SceneView& v = sc->view;
-    bool ok = upload(sc, desc->shapes, (size_t)desc->n_shapes, &v.shapes, "upload shapes")
-           && upload(sc, desc->tri_uvs, (size_t)desc->n_tri_uvs, &v.tri_uvs, "upload tri_uvs")
-           && upload(sc, desc->xforms, (size_t)desc->n_xforms, &v.xforms, "upload xforms")
-           && upload(sc, desc->materials, (size_t)desc->n_materials, &v.materials, "upload materials")
-           && upload(sc, desc->textures, (size_t)desc->n_textures, &v.textures, "upload textures")
-           && upload(sc, desc->texels, (size_t)desc->n_texels, &v.texels, "upload texels")
-           && upload(sc, desc->media, (size_t)desc->n_media, &v.media, "upload media")
-           && upload(sc, desc->bvh_nodes, (size_t)desc->n_bvh_nodes, &v.bvh_nodes, "upload bvh nodes")
-           && upload(sc, desc->bvhs, (size_t)desc->n_bvhs, &v.bvhs, "upload bvhs")
-           && upload(sc, desc->world, (size_t)desc->n_world, &v.world, "upload world")
-           && upload(sc, desc->lights, (size_t)desc->n_lights, &v.lights, "upload lights");
+    bool ok = upload(sc, desc->shapes, (size_t)desc->n_shapes, &v.shapes.p, "upload shapes")
+           && upload(sc, desc->tri_uvs, (size_t)desc->n_tri_uvs, &v.tri_uvs.p, "upload tri_uvs")
+           && upload(sc, desc->xforms, (size_t)desc->n_xforms, &v.xforms.p, "upload xforms")
+           && upload(sc, desc->materials, (size_t)desc->n_materials, &v.materials.p, "upload materials")
+           && upload(sc, desc->textures, (size_t)desc->n_textures, &v.textures.p, "upload textures")
+           && upload(sc, desc->texels, (size_t)desc->n_texels, &v.texels.p, "upload texels")
+           && upload(sc, desc->media, (size_t)desc->n_media, &v.media.p, "upload media")
+           && upload(sc, desc->bvh_nodes, (size_t)desc->n_bvh_nodes, &v.bvh_nodes.p, "upload bvh nodes")
+           && upload(sc, desc->bvhs, (size_t)desc->n_bvhs, &v.bvhs.p, "upload bvhs")
+           && upload(sc, desc->world, (size_t)desc->n_world, &v.world.p, "upload world")
+           && upload(sc, desc->lights, (size_t)desc->n_lights, &v.lights.p, "upload lights");
     if (!ok) { pt_scene_destroy(sc); return PT_ERR_HIP; }
     v.n_world = desc->n_world;
     v.n_lights = desc->n_lights;
@@ -525,15 +525,15 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
         for (int i = 1; i < desc->n_world && in_table_order; i++)     // then the shape index is the tie order
             in_table_order = desc->world[i].index > desc->world[i - 1].index;
         if (in_table_order) {
-            rc = pt::lbvh_build(desc, v.shapes, v.xforms, &d_nodes, &n_nodes, &root, want_wide, &depth, area_sweep);
+            rc = pt::lbvh_build(desc, v.shapes.p, v.xforms.p, &d_nodes, &n_nodes, &root, want_wide, &depth, area_sweep);
             built = true;
         } else {
             if (lbvh_plan(desc, &plan)) {
                 rc = pt::lbvh_build_leaves(plan.leaves.data(), (int)plan.leaves.size(), desc->camera[21], desc->camera[22],
-                                           v.shapes, v.xforms, &d_nodes, &n_nodes, &root, want_wide, &depth, area_sweep);
-                if (rc == PT_OK && !(upload(sc, plan.order.data(), plan.order.size(), &v.lbvh_order, "upload leaf order") &&
-                                     upload(sc, plan.group.data(), plan.group.size(), &v.lbvh_group, "upload leaf groups") &&
-                                     upload(sc, plan.leaf_gate.data(), plan.leaf_gate.size(), &v.ref_leaf_gate, "upload leaf gates"))) {
+                                           v.shapes.p, v.xforms.p, &d_nodes, &n_nodes, &root, want_wide, &depth, area_sweep);
+                if (rc == PT_OK && !(upload(sc, plan.order.data(), plan.order.size(), &v.lbvh_order.p, "upload leaf order") &&
+                                     upload(sc, plan.group.data(), plan.group.size(), &v.lbvh_group.p, "upload leaf groups") &&
+                                     upload(sc, plan.leaf_gate.data(), plan.leaf_gate.size(), &v.ref_leaf_gate.p, "upload leaf gates"))) {
                     (void)hipFree(d_nodes); if (d_wide) (void)hipFree(d_wide); pt_scene_destroy(sc); return PT_ERR_HIP;
                 }
                 v.lbvh_prefix = plan.prefix;
@@ -583,9 +583,9 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
             v.tree_wrapped = wrapped ? 1 : 0;
             if (all.empty()) all.push_back(0.0f);             // never read: every run is empty
             if (members.empty()) members.push_back(0);
-            if (!(upload(sc, all.data(), all.size(), &v.tree_planes, "upload tree planes") &&
-                  upload(sc, first.data(), first.size(), &v.tree_plane_first, "upload tree plane runs") &&
-                  upload(sc, members.data(), members.size(), &v.tree_plane_members, "upload tree plane members"))) {
+            if (!(upload(sc, all.data(), all.size(), &v.tree_planes.p, "upload tree planes") &&
+                  upload(sc, first.data(), first.size(), &v.tree_plane_first.p, "upload tree plane runs") &&
+                  upload(sc, members.data(), members.size(), &v.tree_plane_members.p, "upload tree plane members"))) {
                 (void)hipFree(d_nodes); if (d_wide) (void)hipFree(d_wide); pt_scene_destroy(sc); return PT_ERR_HIP;
             }
         }
@@ -613,8 +613,8 @@ extern "C" int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene)
     // the signature kernels shade from the face table and sample the one light shape: both must exist
     if (sc->variant == V_CORNELL && world_matches(desc, CornellWorld{}) && desc->n_lights == 1 && signature_faces(desc, &faces)) {
         const std::vector<float> table = signature_table(desc);
-        if (!upload(sc, table.data(), table.size(), &v.sig, "upload signature table") ||
-            !upload(sc, faces.data(), faces.size(), &v.sig_faces, "upload signature faces")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
+        if (!upload(sc, table.data(), table.size(), &v.sig.p, "upload signature table") ||
+            !upload(sc, faces.data(), faces.size(), &v.sig_faces.p, "upload signature faces")) { pt_scene_destroy(sc); return PT_ERR_HIP; }
         for (int k = 0; k < 5; k++) v.sig_light[k] = desc->shapes[desc->lights[0]].p[k];
         sc->variant = V_CORNELL_WORLD;
     }
@@ -1168,11 +1168,11 @@ extern "C" int pt_scene_lbvh_wide_nodes(PtScene* sc, void* nodes, size_t capacit
     if (!sc) { pt::set_error("pt_scene_lbvh_wide_nodes: null scene"); return PT_ERR_INVALID; }
     if (!sc->view.lbvh4) return 0;
     size_t bytes = 0;                                         // the array was allocated for exactly its nodes
-    if (!hip_ok(hipMemPtrGetInfo(const_cast<ptd::LbvhNode4*>(sc->view.lbvh4), &bytes), "hipMemPtrGetInfo(wide nodes)")) return PT_ERR_HIP;
+    if (!hip_ok(hipMemPtrGetInfo(const_cast<ptd::LbvhNode4*>(sc->view.lbvh4.p), &bytes), "hipMemPtrGetInfo(wide nodes)")) return PT_ERR_HIP;
     const size_t n = bytes / sizeof(ptd::LbvhNode4);
     if (nodes) {
         if (capacity_bytes < n * sizeof(ptd::LbvhNode4)) { pt::set_error("pt_scene_lbvh_wide_nodes: buffer too small"); return PT_ERR_INVALID; }
-        if (!hip_ok(hipMemcpy(nodes, sc->view.lbvh4, n * sizeof(ptd::LbvhNode4), hipMemcpyDeviceToHost), "hipMemcpy(wide nodes)")) return PT_ERR_HIP;
+        if (!hip_ok(hipMemcpy(nodes, sc->view.lbvh4.p, n * sizeof(ptd::LbvhNode4), hipMemcpyDeviceToHost), "hipMemcpy(wide nodes)")) return PT_ERR_HIP;
     }
     return (int)n;
 }
@@ -1184,7 +1184,7 @@ extern "C" int pt_scene_lbvh_nodes(PtScene* sc, void* nodes, size_t capacity_byt
     const size_t bytes = (size_t)sc->lbvh_nodes * sizeof(LbvhNode);
     if (nodes) {
         if (capacity_bytes < bytes) { pt::set_error("pt_scene_lbvh_nodes: buffer too small"); return PT_ERR_INVALID; }
-        if (!hip_ok(hipMemcpy(nodes, sc->view.lbvh, bytes, hipMemcpyDeviceToHost), "hipMemcpy(lbvh)")) return PT_ERR_HIP;
+        if (!hip_ok(hipMemcpy(nodes, sc->view.lbvh.p, bytes, hipMemcpyDeviceToHost), "hipMemcpy(lbvh)")) return PT_ERR_HIP;
     }
     return sc->lbvh_nodes;
 }

@@ -104,32 +104,79 @@ static_assert(sizeof(LbvhNode4) == 64, "one 64-byte fetch per node");
 // plane q of the grid along one axis, decoded (the walk of the rays that barely move along some axis)
 PT_FN_EARLY float lbvh4_plane(float corner, float step, unsigned q) { return corner + (float)q * step; }
 
+// The scene's arrays are read-only for as long as a kernel runs, and the kernels read them through the constant
+// address space, which says exactly that.  It matters: a load whose address is the same in every lane goes through the
+// scalar unit only if the compiler can show that nothing in the kernel may have written the memory, and an atomic load
+// or store, s_sleep, s_setprio, a clock read or inline assembly anywhere in the kernel makes it give up -- the
+// persistent kernels, which have all of those, then fetched every list entry and every table row through the vector
+// unit, once per lane (a list walk a third slower, 290 more vector instructions per bounce of the rectangle scene's
+// chunk kernel).  Loads through a constant-address-space pointer need no such proof.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_SCENE __attribute__((address_space(4)))
+#else
+#define PT_SCENE                                           // the host pass only parses the device functions
+#endif
+template <class T> struct ScenePtr {
+    const T* p;                                            // a device pointer; the host fills it
+    __device__ __forceinline__ const PT_SCENE T* get() const { return (const PT_SCENE T*)p; }
+    __device__ __forceinline__ const PT_SCENE T& operator[](size_t i) const { return ((const PT_SCENE T*)p)[i]; }
+    __host__ __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+    __host__ __device__ __forceinline__ bool operator==(std::nullptr_t) const { return p == nullptr; }
+    __host__ __device__ __forceinline__ bool operator!=(std::nullptr_t) const { return p != nullptr; }
+    template <class I> __device__ __forceinline__ const PT_SCENE T* operator+(I i) const { return get() + i; }
+    __host__ ScenePtr& operator=(const T* q) { p = q; return *this; }
+};
+// The same interface over an ordinary pointer, for the signature walk's tables: there the compiler's own choice is
+// the better one (scalar loads in the tile kernels, vector loads in the chunk kernels, which are short of scalar
+// registers; rectangle scene 1024^2 x 4096 in chunks: 205.6 ms so, 214.2 with the tables in the constant address
+// space, half of the frame 128.0 against 135.2).
+template <class T> struct PlainPtr {
+    const T* p;
+    __device__ __forceinline__ const T* get() const { return p; }
+    __device__ __forceinline__ const T& operator[](size_t i) const { return p[i]; }
+    __host__ __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+    __host__ __device__ __forceinline__ bool operator==(std::nullptr_t) const { return p == nullptr; }
+    __host__ __device__ __forceinline__ bool operator!=(std::nullptr_t) const { return p != nullptr; }
+    template <class I> __device__ __forceinline__ const T* operator+(I i) const { return p + i; }
+    __host__ PlainPtr& operator=(const T* q) { p = q; return *this; }
+};
+// A whole record out of a scene array (C++ will not copy a struct out of another address space by itself).
+template <class T> __device__ __forceinline__ T scene_load(const PT_SCENE T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
+    union { T v; uint32_t w[sizeof(T) / 4]; } u;
+    const PT_SCENE uint32_t* s = (const PT_SCENE uint32_t*)p;
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; k++) u.w[k] = s[k];
+    return u.v;
+}
+
 struct SceneView {
-    const PtShape*    shapes;
-    const PtTriUV*    tri_uvs;
-    const PtXform*    xforms;
-    const PtMaterial* materials;
-    const PtTexture*  textures;
-    const uint8_t*    texels;
-    const PtMedium*   media;
-    const PtBvhNode*  bvh_nodes;
-    const PtBvh*      bvhs;
-    const PtObject*   world;
-    const int32_t*    lights;
-    const LbvhNode*   lbvh;
-    const LbvhNode4*  lbvh4;    // the 4-wide form of the same tree (kernels compiled with F_LBVH4 walk this one), or nullptr
-    const float*      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
-    const float*      sig_faces;    // signature walk: SIG_FACE floats per (entry, face): the finished surface (see shade_sig); nullptr = none
+    ScenePtr<PtShape>    shapes;
+    ScenePtr<PtTriUV>    tri_uvs;
+    ScenePtr<PtXform>    xforms;
+    ScenePtr<PtMaterial> materials;
+    ScenePtr<PtTexture>  textures;
+    ScenePtr<uint8_t>    texels;
+    ScenePtr<PtMedium>   media;
+    ScenePtr<PtBvhNode>  bvh_nodes;
+    ScenePtr<PtBvh>      bvhs;
+    ScenePtr<PtObject>   world;
+    ScenePtr<int32_t>    lights;
+    ScenePtr<LbvhNode>   lbvh;
+    ScenePtr<LbvhNode4>  lbvh4;    // the 4-wide form of the same tree (kernels compiled with F_LBVH4 walk this one), or nullptr
+    PlainPtr<float>      sig;      // signature walk: SIG_SLOT floats per world entry (see world_entry)
+    PlainPtr<float>      sig_faces;    // signature walk: SIG_FACE floats per (entry, face): the finished surface (see shade_sig); nullptr = none
     float             sig_light[5];  // signature walk: x0, x1, z0, z1, y of the one XZ rectangle that is the light (shade_sig)
-    const int32_t*    lbvh_order;   // per shape: its place in the sequence of tests the in-order walk makes (nullptr: the shape index)
-    const int32_t*    lbvh_group;   // per shape: the reference BVH it is a leaf of, -1 for a list entry (with lbvh_order)
-    const float*      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
+    ScenePtr<int32_t>    lbvh_order;   // per shape: its place in the sequence of tests the in-order walk makes (nullptr: the shape index)
+    ScenePtr<int32_t>    lbvh_group;   // per shape: the reference BVH it is a leaf of, -1 for a list entry (with lbvh_order)
+    ScenePtr<float>      ref_leaf_gate;    // per shape: box of the reference BVH node that names it as a leaf (6 floats; with lbvh_order)
     int32_t lbvh_prefix;        // world entries the LBVH stands for; the list walk continues from there
     int32_t reads_uv;           // the scene has an image texture (the only reader of a hit's uv)
-    const float*      tree_planes;  // plane coordinates of the un-wrapped rectangles and box faces in the LBVH, x planes, then y, then z
+    ScenePtr<float>      tree_planes;  // plane coordinates of the un-wrapped rectangles and box faces in the LBVH, x planes, then y, then z
     int32_t tree_plane_end[3];  // end of each axis' run in tree_planes
-    const int32_t*    tree_plane_first;    // per plane (+1): start of its run in tree_plane_members
-    const int32_t*    tree_plane_members;  // the shapes that have a rectangle in that plane
+    ScenePtr<int32_t>    tree_plane_first;    // per plane (+1): start of its run in tree_plane_members
+    ScenePtr<int32_t>    tree_plane_members;  // the shapes that have a rectangle in that plane
     const SceneView*  self;                // this view in device memory, for code kept out of line
     int32_t tree_wrapped;       // a wrapped rectangle or box is among the LBVH's leaves
     int32_t n_world, n_lights, lights_is_list, ambient_type;
@@ -305,7 +352,8 @@ __device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray& r, 
     return false;
 }
 // MovingSphere::center (include/ptSphere.h:106-109)
-__device__ __forceinline__ V3 msphere_center(const float* q, float time)
+template <class P>
+__device__ __forceinline__ V3 msphere_center(P q, float time)
 {
     V3 c0 = mk(q[0], q[1], q[2]), c1 = mk(q[3], q[4], q[5]);
     return c0 + ((time - q[6]) / (q[7] - q[6])) * (c1 - c0);
@@ -389,8 +437,8 @@ __device__ __forceinline__ bool rect_ok(float ok, const D& dk, float oa, float d
     const bool out_ab = (a < a0) | (a > a1) | (b < b0) | (b > b1);
     return !(out_t | out_ab);
 }
-template <class D>
-__device__ __forceinline__ void box_sel(const float* q, const Ray& r, const D& dx, const D& dy, const D& dz,
+template <class D, class P>
+__device__ __forceinline__ void box_sel(P q, const Ray& r, const D& dx, const D& dy, const D& dz,
                                         float t0, float& closest, int& code, int base)
 {
     const float x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
@@ -405,8 +453,8 @@ __device__ __forceinline__ void box_sel(const float* q, const Ray& r, const D& d
 // Box = list of six rectangles searched with a shrinking upper bound
 // (include/ptRectangle.h:199-217, src/ptHitableList.cu:12-27): a later face wins ties.
 // (dx, dy, dz): the ray's direction components as rect_t takes them.
-template <class D>
-__device__ __forceinline__ bool box_t(const float* q, const Ray& r, const D& dx, const D& dy, const D& dz,
+template <class D, class P>
+__device__ __forceinline__ bool box_t(P q, const Ray& r, const D& dx, const D& dy, const D& dz,
                                       float t0, float t1, float& t, int& face)
 {
     const float x0 = q[0], y0 = q[1], z0 = q[2], x1 = q[3], y1 = q[4], z1 = q[5];
@@ -425,7 +473,8 @@ __device__ __forceinline__ bool box_t(const float* q, const Ray& r, const D& dx,
 // division is the whole division (rcp_refined) divides that way, with one refined reciprocal per axis for the
 // two faces on it: the same quotients bit for bit (numerators too small for that give |t| < 2^-70 either way,
 // below any t0 >= 2^-20, and are turned away by both), 36 + 60 issue slots instead of six IEEE divides' 204.
-__device__ __forceinline__ bool box_t(const float* q, const Ray& r, float t0, float t1, float& t, int& face)
+template <class P>
+__device__ __forceinline__ bool box_t(P q, const Ray& r, float t0, float t1, float& t, int& face)
 {
     const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
     const float big = fmaxf(fmaxf(fmaxf(fabsf(q[0]), fabsf(q[1])), fmaxf(fabsf(q[2]), fabsf(q[3]))), fmaxf(fabsf(q[4]), fabsf(q[5])));
@@ -436,7 +485,8 @@ __device__ __forceinline__ bool box_t(const float* q, const Ray& r, float t0, fl
 }
 // Triangle::hit (src/ptTriangle.cu:28-72): Moller-Trumbore with back-face cull; the value
 // compared against the range and reported is dot(edge2,qvec) WITHOUT the 1/det factor.
-__device__ __forceinline__ bool triangle_t(const float* q, const Ray& r, float t_min, float t_max, float& t)
+template <class P>
+__device__ __forceinline__ bool triangle_t(P q, const Ray& r, float t_min, float t_max, float& t)
 {
     V3 v0 = mk(q[0], q[1], q[2]), v1 = mk(q[3], q[4], q[5]), v2 = mk(q[6], q[7], q[8]);
     V3 edge1 = v1 - v0;
@@ -583,7 +633,8 @@ struct Hit {
 };
 
 // AABB::hit (include/ptAABB.h:30-48)
-__device__ __forceinline__ bool aabb_hit(const float* bmin, const float* bmax, const Ray& r, float tmin, float tmax)
+template <class P>
+__device__ __forceinline__ bool aabb_hit(P bmin, P bmax, const Ray& r, float tmin, float tmax)
 {
     {
         const float invD = 1 / r.d.x;
@@ -618,7 +669,8 @@ __device__ __forceinline__ bool writes_uv(int shape_type)
 }
 
 // AABB::hit with the three reciprocals taken once per ray: 1 / d is the same value at every node.
-__device__ __forceinline__ bool aabb_hit_inv(const float* bmin, const float* bmax, V3 o, V3 inv, float tmin, float tmax)
+template <class P>
+__device__ __forceinline__ bool aabb_hit_inv(P bmin, P bmax, V3 o, V3 inv, float tmin, float tmax)
 {
     {
         float t0 = (bmin[0] - o.x) * inv.x, t1 = (bmax[0] - o.x) * inv.x;
@@ -809,7 +861,8 @@ __device__ __forceinline__ bool list_order_better(const SceneView& sv, float t, 
 // 64 so a wave's pushes hit 64 different banks); deeper entries spill to private memory.
 constexpr int LBVH_LDS_STACK = TREE_LDS_STACK;
 constexpr int LBVH_STACK = 64;
-__device__ __forceinline__ bool slab(const float* bmin, const float* bmax, V3 o, V3 inv, float tmin, float tmax, float& tnear)
+template <class P>
+__device__ __forceinline__ bool slab(P bmin, P bmax, V3 o, V3 inv, float tmin, float tmax, float& tnear)
 {
     float tx0 = (bmin[0] - o.x) * inv.x, tx1 = (bmax[0] - o.x) * inv.x;
     float ty0 = (bmin[1] - o.y) * inv.y, ty1 = (bmax[1] - o.y) * inv.y;
@@ -1359,7 +1412,7 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
             // nothing precedes that tree in the list.  If the box says no -- about once in 10^7 searches
             // on the RTNW final scene -- the ray is searched again the reference's way, in list order.
             if (sv.lbvh_group[id] >= 0) {
-                const float* gate = sv.ref_leaf_gate + 6 * (size_t)id;
+                const PT_SCENE float* gate = sv.ref_leaf_gate + 6 * (size_t)id;
                 const V3 inv = mk(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
                 if (!aabb_hit_inv(gate, gate + 3, r.o, inv, tmin, tmax)) {
                     any = false; closest = tmax; first = 0;
@@ -1371,7 +1424,10 @@ __device__ __forceinline__ bool world_hit(const SceneView& sv, const Ray& r, flo
     const int n = sv.n_world;
     while (true) {
         for (int i = first; i < n; i++) {
-            const PtObject ob = sv.world[i];
+            // Without a tree every lane walks the whole list, entry by entry: the index is the same in all lanes, and
+            // saying so keeps the entries' loads on the scalar unit whatever the control flow around the search looks like.
+            const int entry = (F & F_LBVH) ? i : __builtin_amdgcn_readfirstlane(i);
+            const PtObject ob = sv.world[entry];
             float t; int id = ob.index, face = 0;
             bool hit = false;
             if (!(F & (F_MEDIUM | F_REFBVH)) || ob.type == PT_OBJ_SHAPE) {
@@ -1643,7 +1699,7 @@ __device__ __forceinline__ V3 texture_value(const SceneView& sv, int tex, float 
         int j = f2i_host((1 - v) * ny - 0.001f);
         i = max(0, i); j = max(0, j);
         i = min(i, nx - 1); j = min(j, ny - 1);
-        const uint8_t* d = sv.texels + t.texel_offset + 3 * i + 3 * nx * j;
+        const PT_SCENE uint8_t* d = sv.texels + t.texel_offset + 3 * i + 3 * nx * j;
         return mk((int)d[0] / 255.0f, (int)d[1] / 255.0f, (int)d[2] / 255.0f);
     }
     return mk(t.color[0], t.color[1], t.color[2]);                  // :47-50

@@ -72,7 +72,7 @@ template <uint32_t F, class W>
 __device__ __forceinline__ void face_table_to_lds(const SceneView& sv, float4* lds)
 {
     if constexpr (FaceTable<F, W>::used) {
-        for (int k = threadIdx.x; k < FaceTable<F, W>::float4s; k += blockDim.x) lds[k] = reinterpret_cast<const float4*>(sv.sig_faces)[k];
+        for (int k = threadIdx.x; k < FaceTable<F, W>::float4s; k += blockDim.x) { const float* f = sv.sig_faces + 4 * k; lds[k] = make_float4(f[0], f[1], f[2], f[3]); }
         __syncthreads();
     }
 }

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
         w.rng = lanes.rng; w.pix = lanes.pix;
     }
     if constexpr (WfFaces<F, W>::used) {
-        for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) faces[k] = reinterpret_cast<const float4*>(sv.sig_faces)[k];
+        for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) { const float* f = sv.sig_faces + 4 * k; faces[k] = make_float4(f[0], f[1], f[2], f[3]); }
     }
     if (threadIdx.x < 2) gq.n_ext[threadIdx.x] = 0;
     if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
