@@ -18,24 +18,56 @@ HIPCC = "/opt/rocm/bin/hipcc"
 EXPECTED = {"pt_k_cornell": 3, "pt_k_spheres": 2}
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_chunk_kernels_keep_ticket_and_barriers_in_one_loop(tmp_path):
+@pytest.fixture(scope="module")
+def assembled(tmp_path_factory):
+    """The compiler's assembly of every kernel translation unit, made once for the tests below."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("needs hipcc")
+    out = tmp_path_factory.mktemp("kernel_asm")
     units = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(ROOT, "gpupathtracer_amd", "csrc", "pt_k_*.hip")))
     assert len(units) >= 11
 
     def assemble(unit):
         src = os.path.join(ROOT, "gpupathtracer_amd", "csrc", unit + ".hip")
         subprocess.check_call([HIPCC, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wno-unused-function",
-                               "-S", "--cuda-device-only", "-o", str(tmp_path / (unit + ".hip.s")), src], stderr=subprocess.DEVNULL)
+                               "-S", "--cuda-device-only", "-o", str(out / (unit + ".hip.s")), src], stderr=subprocess.DEVNULL)
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         list(pool.map(assemble, units))
+    return out, units
+
+
+def test_chunk_kernels_keep_ticket_and_barriers_in_one_loop(assembled):
+    tmp_path, units = assembled
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_chunk_kernel_loops.py"), str(tmp_path)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     for unit in units:
         ok = [l for l in r.stdout.splitlines() if l.startswith("ok") and (" " + unit + ".hip.s ") in l.replace("  ", " ")]
         assert len(ok) == EXPECTED.get(unit, 1), "%s: %d\n%s" % (unit, len(ok), r.stdout)
+
+
+def test_list_walks_read_the_scene_through_the_scalar_unit(assembled):
+    """A list walk reads the same entry in every lane.  The persistent kernels (atomic loads and stores, s_sleep,
+    s_setprio, clock reads) once lost every scalar load to the compiler's caution and walked the list through the vector
+    unit, a third slower; the scene is read through the constant address space since.  Every kernel that walks a list
+    without a tree must keep scalar loads inside its loops, whatever its schedule."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from check_scalar_scene_loads import loads_in_loops
+    tmp_path, _ = assembled
+    spheres = (tmp_path / "pt_k_spheres.hip.s").read_text()
+    cornell = (tmp_path / "pt_k_cornell.hip.s").read_text()
+    seen = 0
+    for txt, needle in ((spheres, "k_render_tilesILj153603"), (spheres, "k_render_refillILj153603"), (spheres, "k_render_chunksILj153603"),
+                        (spheres, "k_render_passILj153603"),
+                        (cornell, "k_render_tilesILj556EN3ptd8AnyWorld"), (cornell, "k_render_refillILj556EN3ptd8AnyWorld"),
+                        (cornell, "k_render_chunksILj556EN3ptd8AnyWorld")):
+        found = loads_in_loops(txt, needle)
+        assert len(found) == 1, needle
+        name, scalar, vector = found[0]
+        assert scalar >= 4, "%s: %d scalar loads in its loops (%d vector)" % (name, scalar, vector)
+        seen += 1
+    assert seen == 7
 
 
 def test_the_loop_check_tells_a_stray_barrier_loop_from_block_placement(tmp_path):
