@@ -5,7 +5,8 @@ derived ratios as JSON.  Development tool.
 
     python tools/pmc_collect.py OUT_DIR KERNEL_SUBSTRING -- python3 bench/configs.py --only c1 --quick
 
-The profiled program must follow `--` directly (no env/bash wrappers)."""
+The profiled program must follow `--` directly (no env/bash wrappers).  PMC_PASSES="A B;C D" replaces the default
+counter groups (one pass per `;`-separated group)."""
 import csv
 import glob
 import json
@@ -23,6 +24,9 @@ PASSES = [
 
 
 def main():
+    global PASSES
+    if os.environ.get("PMC_PASSES"):          # other counter groups: "A B C;D E" = two passes
+        PASSES = [g.split() for g in os.environ["PMC_PASSES"].split(";") if g.strip()]
     out_dir, needle = sys.argv[1], sys.argv[2]
     cmd = sys.argv[sys.argv.index("--") + 1:]
     sums = {}
