@@ -13,16 +13,6 @@ echo "== counters of the headline kernel (bench.py quotes their HBM traffic whil
 $T 900 python3 tools/pmc_collect.py $O/pmc_cornell k_render_chunks -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-staged > $O/pmc_cornell.log
 cp $O/pmc_cornell/summary.json $O/pmc_cornell1024x4096_k_render_chunks.json
 mkdir -p profiles/$R && cp $O/pmc_cornell1024x4096_k_render_chunks.json profiles/$R/
-echo "== bench.py default"
-$T 600 python3 bench.py > $O/bench_cornell1024x4096_default.json
-cat $O/bench_cornell1024x4096_default.json
-echo "== bench.py under rocprofv3 --kernel-trace --stats"
-$T 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench --output-format csv -- python3 bench.py --no-cpu-baseline > $O/bench_cornell1024x4096_under_rocprof.json
-cp "$(stats_csv $O/prof_bench)" $O/bench_cornell1024x4096_kernel_stats.csv
-echo "== configs"
-$T 600 python3 bench/configs.py > $O/configs_1gpu.jsonl
-$T 600 rocprofv3 --kernel-trace --stats -d $O/prof_configs --output-format csv -- python3 bench/configs.py > $O/configs_1gpu_under_rocprof.jsonl
-cp "$(stats_csv $O/prof_configs)" $O/configs_1gpu_kernel_stats.csv
 echo "== counters"
 $T 900 python3 tools/pmc_collect.py $O/pmc_shard k_render_tiles -- python3 tools/shard_render.py 8 512 > $O/pmc_shard.log
 cp $O/pmc_shard/summary.json $O/pmc_cornell_eighth_shard.json
@@ -34,6 +24,19 @@ $T 900 python3 tools/pmc_collect.py $O/pmc_c3 k_render_refill -- python3 bench/c
 cp $O/pmc_c3/summary.json $O/pmc_c3_final_list.json
 $T 900 python3 tools/pmc_collect.py $O/pmc_c4 k_render_walk -- python3 bench/configs.py --only c4 --quick > $O/pmc_c4.log
 cp $O/pmc_c4/summary.json $O/pmc_c4_trimesh_walk.json
+cp $O/pmc_c4_trimesh_walk.json profiles/$R/          # bench/configs.py quotes its measured GB/s beside the algorithmic ones
+echo "== bench.py default"
+$T 600 python3 bench.py > $O/bench_cornell1024x4096_default.json
+cat $O/bench_cornell1024x4096_default.json
+echo "== bench.py under rocprofv3 --kernel-trace --stats"
+$T 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench --output-format csv -- python3 bench.py --no-cpu-baseline > $O/bench_cornell1024x4096_under_rocprof.json
+cp "$(stats_csv $O/prof_bench)" $O/bench_cornell1024x4096_kernel_stats.csv
+echo "== configs"
+$T 600 python3 bench/configs.py > $O/configs_1gpu.jsonl
+$T 600 rocprofv3 --kernel-trace --stats -d $O/prof_configs --output-format csv -- python3 bench/configs.py > $O/configs_1gpu_under_rocprof.jsonl
+cp "$(stats_csv $O/prof_configs)" $O/configs_1gpu_kernel_stats.csv
+echo "== sharding estimates"
+$T 600 python3 tools/sharding_estimates.py > $O/sharding_estimates.json
 echo "== staged pipeline"
 $T 900 python3 tools/pmc_collect.py $O/pmc_wf k_wf_groups -- python3 tools/wavefront_render.py 512 > $O/pmc_wf.log
 cp $O/pmc_wf/summary.json $O/pmc_staged_cornell1024x512_k_wf_groups.json
