@@ -741,8 +741,13 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         pt::set_error("render: unknown schedule"); return PT_ERR_INVALID;
     }
     if (p->chunk_samples < 0) { pt::set_error("render: chunk_samples is negative"); return PT_ERR_INVALID; }
-    if (p->schedule == PT_SCHEDULE_CHUNKS && no_alloc) {
-        pt::set_error("pt_render_device_noalloc: PT_SCHEDULE_CHUNKS keeps per-pixel state in memory the scene allocates; use another schedule");
+    // The chunked tiles keep state in a workspace of the scene (states per wave tile, words per group).  The call that may
+    // not allocate takes them only when an earlier pt_render_device call has left the scene a workspace that is large enough.
+    const size_t tile_chunk_bytes = (size_t)ra.n_wave_tiles * 1280 + (4 + 2 * (size_t)ra.n_wave_tiles) * sizeof(unsigned);
+    const bool chunk_workspace_ready = sc->chunk_workspace != nullptr && sc->chunk_workspace_bytes >= tile_chunk_bytes;
+    if (p->schedule == PT_SCHEDULE_CHUNKS && no_alloc && !chunk_workspace_ready) {
+        pt::set_error("pt_render_device_noalloc: PT_SCHEDULE_CHUNKS keeps per-tile state in memory the scene allocates, and no earlier "
+                      "pt_render_device call of this shard size has left it there; make one, or use another schedule");
         return PT_ERR_UNSUPPORTED;
     }
     if (p->schedule == PT_SCHEDULE_WALK && !((sc->mask & ptd::F_LBVH) && sc->view.lbvh_prefix == sc->view.n_world && p->max_depth >= 1)) {
@@ -774,7 +779,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // 28.1 / - / 25.6, a quarter 24.3 / - / 22.4, a sixth 20.6 / - / 21.0; x512 half 18.2 / - / 19.4, a quarter 12.5 / - / 12.5.
     const bool chunks_pay = (sc->variant == V_CORNELL_WORLD || sc->variant == V_FINAL_LBVH4 || sc->variant == V_FINAL_LBVH) &&
                             (ra.n_wave_tiles >= 2 * CHUNK_WAVE_SLOTS || (3 * ra.n_wave_tiles >= 2 * CHUNK_WAVE_SLOTS && p->ns >= 1024));
-    if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill == 0 && ra.n_wave_tiles > 0 && !no_alloc &&
+    if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill == 0 && ra.n_wave_tiles > 0 && (!no_alloc || chunk_workspace_ready) &&
         (p->schedule == PT_SCHEDULE_CHUNKS || (p->schedule == PT_SCHEDULE_AUTO && chunks_pay))) {
         int chunk = p->chunk_samples;
         if (chunk == 0) {
@@ -880,6 +885,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
             const size_t states_bytes = (size_t)ra.n_wave_tiles * 1280;         // CHUNK_TILE_STATE_WORDS 64-bit words per wave tile
             const size_t words_bytes = (4 + 2 * groups) * sizeof(unsigned);      // ticket, cost sum and count; a progress and a cost word per group
             if (sc->chunk_workspace_bytes < states_bytes + words_bytes) {
+                if (no_alloc) { pt::set_error("render: the chunk workspace is too small for a call that may not allocate"); return PT_ERR_UNSUPPORTED; }     // (chunk_workspace_ready said otherwise)
                 if (sc->chunk_workspace) { (void)hipFree(sc->chunk_workspace); sc->chunk_workspace = nullptr; sc->chunk_workspace_bytes = 0; }
                 if (hipMalloc(&sc->chunk_workspace, states_bytes + words_bytes) != hipSuccess) {
                     (void)hipGetLastError();

@@ -128,8 +128,10 @@ enum PtSchedule {
                              * workgroups in order from a device counter, a pixel's random stream and running sum
                              * wait in device memory between its chunks (src/ptMain.cu:156-162 runs them as one
                              * loop), so a frame of few tiles and many samples keeps the GPU full to its end.
-                             * PtRenderParams.chunk_samples sets the chunk.  Keeps 8 bytes per pixel of device
-                             * memory with the scene; PT_ERR_UNSUPPORTED from pt_render_device_noalloc.          */
+                             * PtRenderParams.chunk_samples sets the chunk.  Keeps 20 bytes per pixel of device
+                             * memory with the scene, allocated by the first pt_render_device call that takes this
+                             * schedule for a shard of that size; pt_render_device_noalloc takes the schedule only
+                             * when that memory is already there (PT_ERR_UNSUPPORTED when asked for without it). */
 };
 
 /* Ids reported by pt_trace_closest. */
@@ -328,8 +330,10 @@ int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_
  * pixel-slot counter of the persistent-lane schedules (PT_SCHEDULE_REFILL / _WALK) -- lives in a
  * 256-byte array that is part of the library's device code, one copy per GPU, instead of in memory
  * the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its lane state:
- * PT_ERR_UNSUPPORTED) and not PT_SCHEDULE_CHUNKS, which keeps per-pixel state in memory the scene
- * allocates (PT_ERR_UNSUPPORTED when asked for; PT_SCHEDULE_AUTO never picks it here); at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
+ * PT_ERR_UNSUPPORTED); PT_SCHEDULE_CHUNKS, which keeps per-tile state in memory the scene allocates, only when an
+ * earlier pt_render_device call has left the scene that memory for a shard at least as large (then PT_SCHEDULE_AUTO
+ * picks it here as it does there; without it AUTO runs the tiles whole and asking for CHUNKS is PT_ERR_UNSUPPORTED);
+ * REFILL and WALK uncut; at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
  * counter can number its pixel slots (PT_ERR_INVALID beyond); the scene's device must be current.
  * The counter is cleared at the start of every call.  All calls on one GPU share that GPU's
  * array, whatever the scene or stream: calls that overlap on one GPU race on it and trace pixels

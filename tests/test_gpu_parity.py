@@ -577,7 +577,7 @@ def test_chunked_tiles_schedule_bit_exact(oracle, name, aspect, kw):
 def test_chunked_tiles_large_frames_and_the_lens():
     """Frames with more work items than the GPU holds workgroups (so items wait for their tile's previous chunk
     while others run), against the plain tile schedule's frame; what AUTO picks at the headline's size; the
-    entry point that may not allocate refuses the schedule."""
+    entry point that may not allocate takes the schedule only on a workspace an earlier call left with the scene."""
     tex = np.random.default_rng(5).integers(0, 256, (32, 64, 3), dtype=np.uint8)
     for name, kw, nx, ny, ns, chunk in (("cornell", {}, 1021, 1003, 24, 2), ("cornell", {}, 517, 389, 64, 3),
                                         ("final", dict(earth_rgb=tex, accel=abi.ACCEL_LBVH), 1021, 579, 6, 1),
@@ -599,8 +599,11 @@ def test_chunked_tiles_large_frames_and_the_lens():
     sc.render(1024, 1024, 128, shard_index=0, shard_count=2)
     assert sc.stats().schedule == abi.SCHEDULE_TILES             # a launch of less than two rounds is not cut
     buf = pt.DeviceBuffer(64 * 64 * 12)
-    with pytest.raises(pt.PtError):
-        sc.render_device_noalloc(buf.ptr, 64, 64, 4, schedule=abi.SCHEDULE_CHUNKS)
+    with pytest.raises(pt.PtError):                              # a scene that never rendered in chunks holds no workspace for them
+        pt.Scene(pt.builtin_scene("cornell", 1.0)).render_device_noalloc(buf.ptr, 64, 64, 4, schedule=abi.SCHEDULE_CHUNKS)
+    sc.render_device_noalloc(buf.ptr, 64, 64, 4, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=2)      # this one does, from the frames above
+    pt.synchronize()
+    assert_bit_exact(buf.to_host().reshape(64, 64, 3), sc.render(64, 64, 4, schedule=abi.SCHEDULE_TILES), "chunks through the call that may not allocate")
 
 
 def test_cli_writes_every_image_format(tmp_path, oracle):

@@ -77,6 +77,43 @@ def test_noalloc_render_limits_are_errors():
     assert np.isfinite(frame.to_host()).all()
 
 
+def test_noalloc_render_takes_chunks_once_the_scene_holds_their_workspace():
+    """The chunked tiles keep state in memory the scene allocates on first use.  A call that may not allocate cannot make
+    that memory, but it may use what an earlier pt_render_device call left: then AUTO picks CHUNKS here as it does there
+    (the headline frame is a sixth faster in chunks), and the frames are the same bit for bit.  Without the memory,
+    asking for CHUNKS is an error and AUTO runs the tiles whole."""
+    nx = ny = 512
+    sc = pt.Scene(pt.builtin_scene("cornell", 1.0))
+    frame = pt.DeviceBuffer(nx * ny * 12)
+    with pytest.raises(pt.PtError) as e:
+        sc.render_device_noalloc(frame.ptr, nx, ny, 8, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=4)
+    assert e.value.code == abi.ERR_UNSUPPORTED and "earlier" in str(e.value)
+    sc.render_device_noalloc(frame.ptr, nx, ny, 8)
+    pt.synchronize()
+    assert sc.stats().schedule == abi.SCHEDULE_TILES
+    # an ordinary call in chunks leaves the workspace with the scene ...
+    sc.render_device(frame.ptr, nx, ny, 8, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=4)
+    pt.synchronize()
+    want = frame.to_host().copy()
+    assert sc.stats().schedule == abi.SCHEDULE_CHUNKS and sc.stats().n_chunks == 2
+    # ... and the call that may not allocate runs on it, twice, the second time on a smaller shard
+    for kw in (dict(), dict(shard_index=1, shard_count=3)):
+        frame.from_host(np.full(nx * ny * 3, 7.0, np.float32))
+        sc.render_device_noalloc(frame.ptr, nx, ny, 8, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=4, **kw)
+        pt.synchronize()
+        got = frame.to_host().copy()
+        assert sc.stats().schedule == abi.SCHEDULE_CHUNKS
+        if kw:
+            sc.render_device(frame.ptr, nx, ny, 8, schedule=abi.SCHEDULE_TILES, **kw)
+            pt.synchronize()
+            want = frame.to_host().copy()
+        assert np.array_equal(bits(got), bits(want))
+    # a larger frame than the workspace covers: refused again
+    big = pt.DeviceBuffer(1024 * 1024 * 12)
+    with pytest.raises(pt.PtError):
+        sc.render_device_noalloc(big.ptr, 1024, 1024, 8, schedule=abi.SCHEDULE_CHUNKS, chunk_samples=4)
+
+
 def _hip_runtime():
     """The HIP runtime libptcore.so itself is linked against (already mapped: no second runtime is loaded)."""
     import ctypes
