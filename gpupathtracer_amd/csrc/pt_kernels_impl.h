@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             Hit h;
             h.id = PT_ID_MISS; h.face = 0; h.t = FLT_MAX; h.uv_id = PT_ID_MISS; h.uv_face = 0; h.uv_t = 0.0f;
             bool any = w.any;
+            bool searched_in_order = false;                      // the whole list was walked the reference's way: nothing is left to second-guess
             if (any) { h.t = w.best; h.id = w.best_id; h.face = w.best_face; }
             if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray))) {     // see accepts_nan: the list, in order
                 const InPlaneHit got = lbvh_in_plane_t<F>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z, st.ray.d.x, st.ray.d.y, st.ray.d.z,
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
                         if (any) { h.t = lw.t; h.id = lw.id; h.face = lw.face; }
                     } else {
                         any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+                        searched_in_order = true;
                     }
                 } else {
                     any = got.found > 0;
@@ -553,10 +555,24 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
                     if (any) { h.t = got.t; h.id = got.id; h.face = got.face; }
                 }
             }
+            if constexpr ((F & F_REFBVH) != 0) {
+                // The nearest leaf came out of a reference BVH whose leaves are in the library's tree: the reference only
+                // finds it if the boxes above it let the ray in (see world_hit: the box of the node that names the leaf
+                // decides, and can turn away a ray that grazes an edge although the leaf's own test accepts it).  Such a ray
+                // is searched again the reference's way, in list order.
+                if (!searched_in_order && any && sv.lbvh_group && h.id >= 0 && sv.lbvh_group[h.id] >= 0) {
+                    const PT_SCENE float* gate = sv.ref_leaf_gate + 6 * (size_t)h.id;
+                    const V3 inv = mk(1 / st.ray.d.x, 1 / st.ray.d.y, 1 / st.ray.d.z);
+                    if (!aabb_hit_inv(gate, gate + 3, st.ray.o, inv, 0.001f, FLT_MAX)) {
+                        any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
+                        searched_in_order = true;
+                    }
+                }
+            }
             if (F & F_IMAGE) {
                 // a plain sphere whose texture reads uv shows the uv of the hit the in-order walk accepted
                 // before it, which the tree does not know: that ray is searched again in list order
-                if (sv.reads_uv && any && hit_reads_stale_uv<F>(sv, h.id))
+                if (!searched_in_order && sv.reads_uv && any && hit_reads_stale_uv<F>(sv, h.id))
                     any = world_hit<(F & ~F_LBVH), AnyWorld>(sv, st.ray, 0.001f, FLT_MAX, h, st.rng, my_stack);
             }
             bool ended;
