@@ -536,8 +536,11 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             bool searched_in_order = false;                      // the whole list was walked the reference's way: nothing is left to second-guess
             if (any) { h.t = w.best; h.id = w.best_id; h.face = w.best_face; }
             if (accepts_nan<F>::value && (w.odd || !ray_may_enter_tree(sv, st.ray))) {     // see accepts_nan: the list, in order
-                const InPlaneHit got = lbvh_in_plane_t<F>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z, st.ray.d.x, st.ray.d.y, st.ray.d.z,
-                                                          st.ray.time, 0.001f, FLT_MAX);
+                // the few-candidates shortcut is for worlds of plain list entries: leaves of a reference BVH follow that tree's
+                // own tie rule, and an image texture needs the in-order walk's record of the last uv written (as in world_hit)
+                InPlaneHit got; got.found = -1; got.t = FLT_MAX; got.id = -1; got.face = 0;
+                if constexpr ((F & (F_REFBVH | F_IMAGE)) == 0)
+                    got = lbvh_in_plane_t<F>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z, st.ray.d.x, st.ray.d.y, st.ray.d.z, st.ray.time, 0.001f, FLT_MAX);
                 if (got.found < 0) {
                     if constexpr ((F & (F_MEDIUM | F_REFBVH | F_IMAGE)) == 0) {
                         const ListWalkHit lw = list_walk_out_of_line<(F & ~(F_LBVH | F_LBVH4))>(sv.self, st.ray.o.x, st.ray.o.y, st.ray.o.z,
