@@ -208,26 +208,31 @@ PT_HD uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 PT_HD double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 
 // ---- logf: 16-interval table + degree-3 polynomial in double ----------------------------------
+// One 16-byte row per interval, read with the lane's own index: on the device the array lives in constant memory and a
+// lookup is one load.  (Written as a switch over the index, the sixteen rows became thirty-two double constants that the
+// compiler kept in registers across the kernels' bounce loop -- that is, in scratch memory, reloaded through a tree of
+// branches at every lookup.)
 PT_HD void logf_entry(int i, double* invc, double* logc)
 {
-    switch (i) {
-    case 0: *invc = 0x1.661ec79f8f3bep+0; *logc = -0x1.57bf7808caadep-2; break;
-    case 1: *invc = 0x1.571ed4aaf883dp+0; *logc = -0x1.2bef0a7c06ddbp-2; break;
-    case 2: *invc = 0x1.49539f0f010bp+0; *logc = -0x1.01eae7f513a67p-2; break;
-    case 3: *invc = 0x1.3c995b0b80385p+0; *logc = -0x1.b31d8a68224e9p-3; break;
-    case 4: *invc = 0x1.30d190c8864a5p+0; *logc = -0x1.6574f0ac07758p-3; break;
-    case 5: *invc = 0x1.25e227b0b8eap+0; *logc = -0x1.1aa2bc79c81p-3; break;
-    case 6: *invc = 0x1.1bb4a4a1a343fp+0; *logc = -0x1.a4e76ce8c0e5ep-4; break;
-    case 7: *invc = 0x1.12358f08ae5bap+0; *logc = -0x1.1973c5a611cccp-4; break;
-    case 8: *invc = 0x1.0953f419900a7p+0; *logc = -0x1.252f438e10c1ep-5; break;
-    case 9: *invc = 0x1p+0; *logc = 0x0p+0; break;
-    case 10: *invc = 0x1.e608cfd9a47acp-1; *logc = 0x1.aa5aa5df25984p-5; break;
-    case 11: *invc = 0x1.ca4b31f026aap-1; *logc = 0x1.c5e53aa362eb4p-4; break;
-    case 12: *invc = 0x1.b2036576afce6p-1; *logc = 0x1.526e57720db08p-3; break;
-    case 13: *invc = 0x1.9c2d163a1aa2dp-1; *logc = 0x1.bc2860d22477p-3; break;
-    case 14: *invc = 0x1.886e6037841edp-1; *logc = 0x1.1058bc8a07ee1p-2; break;
-    default: *invc = 0x1.767dcf5534862p-1; *logc = 0x1.4043057b6ee09p-2; break;
-    }
+    alignas(16) const double t[16][2] = {
+        { 0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2 },
+        { 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2 },
+        { 0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2 },
+        { 0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3 },
+        { 0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3 },
+        { 0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3 },
+        { 0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4 },
+        { 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4 },
+        { 0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5 },
+        { 0x1p+0, 0x0p+0 },
+        { 0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5 },
+        { 0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4 },
+        { 0x1.b2036576afce6p-1, 0x1.526e57720db08p-3 },
+        { 0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3 },
+        { 0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2 },
+        { 0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2 },
+    };
+    *invc = t[i][0]; *logc = t[i][1];
 }
 PT_HD float logf_glibc(float x)
 {
@@ -257,26 +262,28 @@ PT_HD float logf_glibc(float x)
 }
 
 // ---- powf(x, 5.0f): log2 table kernel, then exp2 table kernel, both scaled by 32 ------------------
+// Rows as in logf_entry: one load per lookup.
 PT_HD void powf_log2_entry(int i, double* invc, double* logc)
 {
-    switch (i) {
-    case 0: *invc = 0x1.661ec79f8f3bep+0; *logc = -0x1.efec65b963019p-2 * 32; break;
-    case 1: *invc = 0x1.571ed4aaf883dp+0; *logc = -0x1.b0b6832d4fca4p-2 * 32; break;
-    case 2: *invc = 0x1.49539f0f010bp+0; *logc = -0x1.7418b0a1fb77bp-2 * 32; break;
-    case 3: *invc = 0x1.3c995b0b80385p+0; *logc = -0x1.39de91a6dcf7bp-2 * 32; break;
-    case 4: *invc = 0x1.30d190c8864a5p+0; *logc = -0x1.01d9bf3f2b631p-2 * 32; break;
-    case 5: *invc = 0x1.25e227b0b8eap+0; *logc = -0x1.97c1d1b3b7afp-3 * 32; break;
-    case 6: *invc = 0x1.1bb4a4a1a343fp+0; *logc = -0x1.2f9e393af3c9fp-3 * 32; break;
-    case 7: *invc = 0x1.12358f08ae5bap+0; *logc = -0x1.960cbbf788d5cp-4 * 32; break;
-    case 8: *invc = 0x1.0953f419900a7p+0; *logc = -0x1.a6f9db6475fcep-5 * 32; break;
-    case 9: *invc = 0x1p+0; *logc = 0x0p+0; break;
-    case 10: *invc = 0x1.e608cfd9a47acp-1; *logc = 0x1.338ca9f24f53dp-4 * 32; break;
-    case 11: *invc = 0x1.ca4b31f026aap-1; *logc = 0x1.476a9543891bap-3 * 32; break;
-    case 12: *invc = 0x1.b2036576afce6p-1; *logc = 0x1.e840b4ac4e4d2p-3 * 32; break;
-    case 13: *invc = 0x1.9c2d163a1aa2dp-1; *logc = 0x1.40645f0c6651cp-2 * 32; break;
-    case 14: *invc = 0x1.886e6037841edp-1; *logc = 0x1.88e9c2c1b9ff8p-2 * 32; break;
-    default: *invc = 0x1.767dcf5534862p-1; *logc = 0x1.ce0a44eb17bccp-2 * 32; break;
-    }
+    alignas(16) const double t[16][2] = {
+        { 0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2 * 32 },
+        { 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2 * 32 },
+        { 0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2 * 32 },
+        { 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2 * 32 },
+        { 0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2 * 32 },
+        { 0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3 * 32 },
+        { 0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3 * 32 },
+        { 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4 * 32 },
+        { 0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5 * 32 },
+        { 0x1p+0, 0x0p+0 },
+        { 0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4 * 32 },
+        { 0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3 * 32 },
+        { 0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3 * 32 },
+        { 0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2 * 32 },
+        { 0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2 * 32 },
+        { 0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2 * 32 },
+    };
+    *invc = t[i][0]; *logc = t[i][1];
 }
 // bits of 2^(i/32) with i << 47 taken off the exponent field
 PT_HD uint64_t exp2_entry(int i)
