@@ -812,6 +812,43 @@ __device__ __forceinline__ bool medium_t(const SceneView& sv, int m, const Ray& 
 {
     const PtMedium med = sv.media[m];
     float ta, tb; int face;
+    if constexpr ((F & F_SPHERE) != 0) {
+        // A plain sphere as the boundary (both volumes of the final scene): the two boundary searches
+        // (include/ptMedium.h:35-36) evaluate the same quadratic of the same ray and differ in the range they
+        // accept a root in, so the roots are computed once.  Sphere::hit (src/ptSphere.cu:11-40) takes the
+        // near root when it lies in the range, else the far one; computing a root it would not have looked at
+        // changes no value.
+        const PtShape* s = &sv.shapes[med.boundary];
+        if (s->type == PT_SHAPE_SPHERE && (!(F & F_XFORM) || s->xform_count == 0)) {
+            const V3 oc = r.o - mk(s->p[0], s->p[1], s->p[2]);
+            const float radius = s->p[3];
+            const float a = dot(r.d, r.d);
+            const float b = dot(oc, r.d);
+            const float c = dot(oc, oc) - radius * radius;
+            const float disc = b * b - a * c;
+            if (!(disc > 0)) return false;
+            const float sq = sqrtf(disc);
+            const float near_root = (-b - sq) / a, far_root = (-b + sq) / a;
+            if (near_root < FLT_MAX && near_root > -FLT_MAX) ta = near_root;
+            else if (far_root < FLT_MAX && far_root > -FLT_MAX) ta = far_root;
+            else return false;
+            const float from = (float)((double)ta + 0.0001);
+            if (near_root < FLT_MAX && near_root > from) tb = near_root;
+            else if (far_root < FLT_MAX && far_root > from) tb = far_root;
+            else return false;
+            if (ta < t0) ta = t0;
+            if (tb > t1) tb = t1;
+            if (ta > tb) return false;
+            if (ta < 0) ta = 0;
+            const float dist_inside = (tb - ta) * len(r.d);
+            const float hit_dist = -(1 / med.density) * ptm::logf_glibc(g.rand());
+            if (hit_dist < dist_inside) {
+                t = ta + hit_dist / len(r.d);
+                return true;
+            }
+            return false;
+        }
+    }
     if (shape_t<F>(sv, med.boundary, r, -FLT_MAX, FLT_MAX, ta, face)) {
         if (shape_t<F>(sv, med.boundary, r, (float)((double)ta + 0.0001), FLT_MAX, tb, face)) {
             if (ta < t0) ta = t0;
