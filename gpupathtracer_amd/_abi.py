@@ -85,7 +85,7 @@ class PtRenderParams(C.Structure):
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32),
                 ("pipeline", C.c_int32), ("schedule", C.c_int32), ("batch_index", C.c_int32), ("batch_count", C.c_int32),
-                ("raw_sum", C.c_int32), ("chunk_samples", C.c_int32), ("stage_stats", C.c_int32), ("reserved", C.c_int32)]
+                ("raw_sum", C.c_int32), ("chunk_samples", C.c_int32), ("stage_stats", C.c_int32), ("slot_block_tiles", C.c_int32)]
 
 
 class PtRay(C.Structure):

@@ -314,11 +314,11 @@ class RenderStats:
 
 
 def make_params(nx, ny, ns, max_depth=25, shard_index=0, shard_count=1, tile=(8, 8), pipeline=0, schedule=0,
-                batch_index=0, batch_count=0, raw_sum=0, chunk_samples=0, stage_stats=0):
+                batch_index=0, batch_count=0, raw_sum=0, chunk_samples=0, stage_stats=0, slot_block_tiles=0):
     return A.PtRenderParams(nx=nx, ny=ny, ns=ns, max_depth=max_depth, shard_index=shard_index,
                             shard_count=shard_count, tile_w=tile[0], tile_h=tile[1], pipeline=pipeline, schedule=schedule,
                             batch_index=batch_index, batch_count=batch_count, raw_sum=raw_sum, chunk_samples=chunk_samples,
-                            stage_stats=stage_stats)
+                            stage_stats=stage_stats, slot_block_tiles=slot_block_tiles)
 
 
 class Scene:

@@ -825,6 +825,12 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         }
     }
     ra.chunk_priority = 1;
+    // Pixel slots of the persistent-lane schedules from one counter per XCD (slot_band_draw).  One counter against eight with
+    // blocks of 64 wave tiles (kernel ms): 2 M triangles 3840x2160 x16 49.1 -> 40.4, x64 154.3 -> 153.6 (blocks of 8 / 32 / 256 /
+    // 1024: x16 40.7 / 40.0 / 41.2 / 41.0); random spheres in the tree 1920x1080 x16 12.2 -> 9.7, x256 132.5 -> 129.5, 3840x2160 x64
+    // 139.2 -> 127.2.
+    ra.slot_bands = p->slot_block_tiles < 0 ? 1 : 8;
+    ra.band_block_tiles = p->slot_block_tiles > 0 ? p->slot_block_tiles : 64;
     ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
@@ -866,7 +872,8 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         sc->last.pipeline = PT_PIPELINE_WAVEFRONT;
     } else {
         // the counter keeps the last call's final value: it starts every call at zero
-        if (!hip_ok(hipMemsetAsync(slot_counter, 0, sizeof(unsigned), st), "hipMemsetAsync(slot counter)")) return PT_ERR_HIP;
+        // (the whole 256-byte block: the shared walk counts in up to eight words of it, one per band of slots)
+        if (!hip_ok(hipMemsetAsync(slot_counter, 0, PT_SCRATCH_BYTES, st), "hipMemsetAsync(slot counters)")) return PT_ERR_HIP;
         if (ra.n_chunks > 0 && ra.refill != 0) {
             const size_t rec_bytes = (size_t)p->nx * (size_t)p->ny * 5 * sizeof(unsigned long long);     // CHUNK_REC_WORDS per pixel
             if (sc->chunk_workspace_bytes < rec_bytes) {

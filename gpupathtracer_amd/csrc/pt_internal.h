@@ -19,6 +19,8 @@ struct RenderArgs {
     int32_t n_wave_tiles;          // wave tiles owned by this shard
     int32_t refill;                // fused scheduler: 1 persistent lanes that pull pixel slots from a counter, 2 the same with the shared tree walk
     int32_t walk_wait;             // shared walk: lanes with a finished search that make the wave leave the search loop
+    int32_t slot_bands;            // persistent-lane schedules: 1, or 8 = pixel slots drawn from eight counters, a wave starting with its XCD's (slot_band_draw)
+    int32_t band_block_tiles;      // ... in blocks of this many wave tiles, block k in band k mod 8
     int32_t raw_sum;               // write the plain sample sums instead of sqrt(sum / ns)
     uint64_t seed_offset;          // added to the pixel index before seeding (sample batches; 0 = the reference's stream)
     int32_t chunk_samples, n_chunks;   // chunked tiles: samples per work item and items per tile (0: not chunked)

@@ -408,12 +408,47 @@ __device__ __forceinline__ bool chunk_record_load(unsigned long long* __restrict
     }
     return whole;
 }
-// Slot -> (chunk, pixel slot of the shard): chunk-major, so that every pixel's chunk c is handed out before any
-// pixel's chunk c + 1.  n_chunks <= 1: the slot is the pixel slot.
-__device__ __forceinline__ void slot_chunk(const RenderArgs& ra, unsigned total_slots, unsigned slot, unsigned& c, unsigned& pixel_slot)
+// ---- pixel slots from one counter per XCD ---------------------------------------------------------------
+// The persistent-lane schedules hand out pixel slots (64 per 8x8 wave tile; with chunks, (chunk, pixel) pairs) from a
+// device counter, one atomic per wave for all its lanes that ran dry.  One word serves one atomic at a time, about 22 ns
+// each with the eight XCDs asking, and a launch of few samples a pixel asks often: random spheres 1920x1080 at 16
+// samples spent a fifth of its time there.  So the shard's wave tiles are dealt to eight counters in blocks (block k
+// to counter k mod 8) and a wave draws from the counter of the XCD it runs on (its id is in a hardware register); a
+// wave whose counter has run dry moves on to the next, so the shard still ends with every lane busy.  The eight
+// sweeps advance side by side along one front.  (Eight contiguous bands of the frame instead -- each XCD's L2 then
+// sees its own eighth of a scene too large for one -- were 12 % slower on 2 M triangles at 64 samples: eight fronts
+// far apart share little in the Infinity Cache, and that outweighs what the L2s gain.)  Which lane traces a pixel
+// changes no value.  The counters sit 32 bytes apart in the 256-byte counter block.
+constexpr int SLOT_BANDS = 8, SLOT_BAND_STRIDE = 8;
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7; }      // hwreg(HW_REG_XCC_ID, 0, 4)
+// The j-th draw from `band`: false when the band has no slot j (it is dry); else the chunk and pixel slot, chunk-major
+// within the band, so that a pixel's chunk c - 1 is always drawn -- from this same counter -- before its chunk c.
+__device__ __forceinline__ bool slot_band_draw(const RenderArgs& ra, int band, unsigned j, unsigned& c, unsigned& pixel_slot)
 {
-    c = 0; pixel_slot = slot;
-    if (ra.n_chunks > 1) { c = slot / total_slots; pixel_slot = slot - c * total_slots; }
+    const unsigned tiles = (unsigned)ra.n_wave_tiles;
+    const unsigned chunks = (unsigned)max(1, ra.n_chunks);
+    if (ra.slot_bands <= 1) {                                 // one sweep of the shard
+        const unsigned pixels = tiles * 64u;
+        if (j >= pixels * chunks) return false;               // the host keeps the shard's slots times chunks below 2^32
+        c = ra.n_chunks > 1 ? j / pixels : 0u;
+        pixel_slot = j - c * pixels;
+        return true;
+    }
+    // blocks of B wave tiles, block k in band k mod 8: the bands' sweeps advance side by side along one front
+    const unsigned B = (unsigned)ra.band_block_tiles;
+    const unsigned n_blocks = (tiles + B - 1) / B;
+    const unsigned b = (unsigned)band;
+    const unsigned my_blocks = n_blocks > b ? (n_blocks - b + (unsigned)SLOT_BANDS - 1) / (unsigned)SLOT_BANDS : 0u;
+    unsigned band_tiles = my_blocks * B;
+    if (my_blocks > 0 && (n_blocks - 1) % (unsigned)SLOT_BANDS == b) band_tiles -= n_blocks * B - tiles;      // the shard's last block is this band's last, and short
+    const unsigned band_pixels = band_tiles * 64u;
+    if (j >= band_pixels * chunks) return false;
+    c = ra.n_chunks > 1 ? j / band_pixels : 0u;
+    const unsigned in_chunk = j - c * band_pixels;
+    const unsigned tile_in_band = in_chunk >> 6;
+    const unsigned block = tile_in_band / B;
+    pixel_slot = ((block * (unsigned)SLOT_BANDS + b) * B + (tile_in_band - block * B)) * 64u + (in_chunk & 63u);
+    return true;
 }
 
 // Fused scheduler with persistent lanes: a lane that has finished its pixel takes the next pixel
@@ -432,9 +467,10 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane] : nullptr;
-    const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
-    const unsigned all_slots = total_slots * (unsigned)max(1, ra.n_chunks);       // the host keeps this below 2^32
     const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
+    const int home_band = ra.slot_bands > 1 ? xcc_id() : 0;   // see slot_band_draw
+    int bands_dry = 0;                                        // bands this wave has found empty (the same number in all its lanes)
+    bool band_dry = false;
     LaneState st;
     lane_init(st);
     unsigned i = 0;
@@ -442,18 +478,20 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_refill(Scen
     unsigned need_chunks = 0, wait_from = 0;          // need_chunks > 0: the slot is held, the record of the pixel's earlier chunks is not there yet
     bool have = false;
     while (true) {
+        // the lanes still in the loop are all here: the wave moves on to the next band together, and a lane that found the last one dry is done
+        if (__ballot(band_dry) != 0ull) bands_dry++;
+        if (band_dry) { band_dry = false; if (bands_dry >= ra.slot_bands) break; }     // the shard is exhausted
         const bool wave_busy = __ballot(have) != 0ull;
         if (!have && need_chunks == 0) {
+            const int band = ra.slot_bands > 1 ? ((home_band + bands_dry) & (SLOT_BANDS - 1)) : 0;
             const unsigned long long need = __ballot(1);  // one atomic per wave for all lanes that ran dry
             const int leader = __ffsll((long long)need) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(next_slot, (unsigned)__popcll(need));
+            if (lane == leader) base = atomicAdd(next_slot + band * SLOT_BAND_STRIDE, (unsigned)__popcll(need));
             base = __shfl(base, leader);
             const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const unsigned slot = base + (unsigned)__popcll(need & lower);
-            if (slot >= all_slots) break;                 // the shard is exhausted: this lane is done
-            unsigned c, ps;
-            slot_chunk(ra, total_slots, slot, c, ps);
+            unsigned c = 0, ps = 0;
+            if (!slot_band_draw(ra, band, base + (unsigned)__popcll(need & lower), c, ps)) { band_dry = true; continue; }     // ask the next band, or stop (above)
             int x, ytop;
             if (!wave_pixel(ra, (int)(ps >> 6), (int)(ps & 63), x, ytop)) continue;   // slot beyond the image edge
             lane_begin_pixel(st, ra, x, ytop, i);
@@ -512,9 +550,9 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     int* my_stack = &lds_stack[wave_in_block * 64 * LBVH_LDS_STACK + lane];
-    const unsigned total_slots = (unsigned)ra.n_wave_tiles * 64u;
-    const unsigned all_slots = total_slots * (unsigned)max(1, ra.n_chunks);       // the host keeps this below 2^32
     const Rcp fnx = rcp_refined((float)ra.nx), fny = rcp_refined((float)ra.ny);     // loop-invariant
+    const int home_band = ra.slot_bands > 1 ? xcc_id() : 0;   // see slot_band_draw
+    int bands_dry = 0;                                        // bands this wave has found empty (the same number in all its lanes)
     enum { NEED_PIXEL, NEED_RECORD, NEXT_RAY, WALKING, WALKED, DONE };
     int ns_end = ra.ns;                                       // where this lane's work item ends: the pixel's last sample or a chunk's
     unsigned wait_from = 0;
@@ -604,18 +642,18 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
         }
         pf.mark(PROF_SHADE, walked_lanes);
         PROF_LANES(pixel_lanes, mode == NEED_PIXEL);
+        bool band_dry = false;
         if (mode == NEED_PIXEL) {
+            const int band = ra.slot_bands > 1 ? ((home_band + bands_dry) & (SLOT_BANDS - 1)) : 0;
             const unsigned long long need = __ballot(1);      // one atomic per wave for all lanes that ran dry
             const int leader = __ffsll((long long)need) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(next_slot, (unsigned)__popcll(need));
+            if (lane == leader) base = atomicAdd(next_slot + band * SLOT_BAND_STRIDE, (unsigned)__popcll(need));
             base = __shfl(base, leader);
             const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const unsigned slot = base + (unsigned)__popcll(need & lower);
-            unsigned c, ps;
-            slot_chunk(ra, total_slots, slot, c, ps);
+            unsigned c = 0, ps = 0;
             int x, ytop;
-            if (slot >= all_slots) mode = DONE;               // the shard is exhausted
+            if (!slot_band_draw(ra, band, base + (unsigned)__popcll(need & lower), c, ps)) band_dry = true;     // ask the next band, or stop (below)
             else if (wave_pixel(ra, (int)(ps >> 6), (int)(ps & 63), x, ytop)) {
                 lane_begin_pixel(st, ra, x, ytop, i);
                 ns_end = ra.n_chunks > 1 ? min(ra.ns, (int)(c + 1) * ra.chunk_samples) : ra.ns;
@@ -624,6 +662,9 @@ __global__ __launch_bounds__(256, fused_min_blocks(F)) void k_render_walk(SceneV
             }
             // else: a slot beyond the image edge; ask again next round
         }
+        // every lane of the wave is here: the wave moves on to the next band together, and a lane that found the last one dry is done
+        if (__ballot(band_dry) != 0ull) bands_dry++;
+        if (band_dry && bands_dry >= ra.slot_bands) mode = DONE;      // the shard is exhausted
         pf.mark(PROF_PIXEL, pixel_lanes);
         PROF_LANES(record_lanes, mode == NEED_RECORD);
         if (mode == NEED_RECORD) {                            // the state the pixel's earlier chunks left; not there yet: ask again next round

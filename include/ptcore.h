@@ -236,7 +236,10 @@ typedef struct PtRenderParams {
     int32_t chunk_samples; /* PT_SCHEDULE_CHUNKS, _REFILL, _WALK (and what AUTO picks): samples per chunk; 0 = the library's choice */
     int32_t stage_stats;   /* PT_PIPELINE_WAVEFRONT: != 0 counts what the stages did, for pt_render_stage_stats (a kernel of
                             * its own: the counting costs the rectangle scene's staged render about 6 % of its rate)      */
-    int32_t reserved;
+    int32_t slot_block_tiles; /* PT_SCHEDULE_REFILL, _WALK (and AUTO where it picks them): how lanes draw pixel slots.  0 = the library's choice;
+                               * > 0: from eight counters, one per XCD of the GPU, wave tiles dealt to them in blocks of this
+                               * many (block k to counter k mod 8; a wave whose counter has run dry moves on to the next);
+                               * < 0: from one counter, one sweep of the shard.  Changes no pixel.                            */
 } PtRenderParams;
 
 /* One ray for pt_trace_closest.  The hit range is the integrator's [0.001, FLT_MAX]

@@ -1210,6 +1210,40 @@ def test_shared_walk_schedule_bit_exact(oracle, which):
     assert_bit_exact(sc.render(8, 8, 2, 0), oracle.render(d, 8, 8, 2, 0), which + " depth 0 under AUTO")
 
 
+@pytest.mark.parametrize("which", ["random", "trimesh"])
+def test_pixel_slots_from_a_counter_per_xcd_bit_exact(oracle, which):
+    """The lanes of the persistent-lane schedules (REFILL, WALK) draw pixel slots from eight counters, one per XCD, wave tiles dealt to them in blocks
+    (PtRenderParams.slot_block_tiles); a wave whose counter has run dry moves on to the next.  Which lane traces a
+    pixel changes no value: blocks of one tile, a size that leaves the last block short, more blocks than tiles,
+    with the samples in chunks (a pixel's chunks are drawn from one counter, in order), on a shard, and against the
+    one-counter sweep on a frame with more pixels than the GPU has lanes."""
+    if which == "trimesh":
+        d = pt.trimesh_scene(12, 1.0)
+        d.c.accel = abi.ACCEL_LBVH
+    else:
+        d = pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)
+    sc = pt.Scene(d)
+    for nx, ny, ns in ((72, 40, 7), (8, 8, 9), (3, 2, 5)):
+        ref = oracle.render(d, nx, ny, ns)
+        for block in (1, 3, 64, -1):
+            for schedule in (abi.SCHEDULE_WALK, abi.SCHEDULE_REFILL):
+                img = sc.render(nx, ny, ns, schedule=schedule, slot_block_tiles=block)
+                assert_bit_exact(img, ref, "%s %dx%dx%d schedule %d blocks of %d" % (which, nx, ny, ns, schedule, block))
+                assert sc.stats().schedule == schedule
+                for chunk in (1, 3):
+                    img = sc.render(nx, ny, ns, schedule=schedule, slot_block_tiles=block, chunk_samples=chunk)
+                    assert_bit_exact(img, ref, "%s %dx%dx%d schedule %d blocks of %d, chunks of %d" % (which, nx, ny, ns, schedule, block, chunk))
+    ref = oracle.render(d, 72, 40, 7, shard_index=1, shard_count=3)
+    assert_bit_exact(sc.render(72, 40, 7, schedule=abi.SCHEDULE_WALK, slot_block_tiles=2, chunk_samples=2, shard_index=1, shard_count=3), ref,
+                     which + " shard, blocks of 2, chunks of 2")
+    nx, ny, ns = 1024, 640, 32
+    sweep = sc.render(nx, ny, ns, schedule=abi.SCHEDULE_WALK, slot_block_tiles=-1)
+    for block in (5, 64, 4096):
+        assert_bit_exact(sc.render(nx, ny, ns, schedule=abi.SCHEDULE_WALK, slot_block_tiles=block), sweep, "%s %dx%dx%d blocks of %d" % (which, nx, ny, ns, block))
+    assert_bit_exact(sc.render(nx, ny, 4, schedule=abi.SCHEDULE_REFILL, slot_block_tiles=7), sc.render(nx, ny, 4, schedule=abi.SCHEDULE_REFILL, slot_block_tiles=-1),
+                     which + " refill, blocks of 7")
+
+
 @pytest.mark.parametrize("which", ["random", "cornell", "final", "final_tree", "trimesh"])
 def test_persistent_lane_schedules_in_chunks_bit_exact(oracle, which):
     """REFILL and WALK with every pixel's samples cut into chunks: slots are (chunk, pixel), the pixel's random

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time of one scene at one size: python tools/quick_time.py cornell 1024 1024 256 [lbvh] [schedule N] [chunk SAMPLES] [shards N] [wavefront]
+"""Kernel time of one scene at one size: python tools/quick_time.py cornell 1024 1024 256 [lbvh] [schedule N] [chunk SAMPLES] [shards N] [bands N] [wavefront]
 Development tool."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +18,8 @@ if "chunk" in rest:                       # with `schedule 2|3`: the persistent-
     kw["chunk_samples"] = int(rest[rest.index("chunk") + 1])
 if "wavefront" in rest:
     kw["pipeline"] = abi.PIPELINE_WAVEFRONT
+if "bands" in rest:                     # pixel slots of the shared walk: blocks of N wave tiles over eight counters (< 0: one counter)
+    kw["slot_block_tiles"] = int(rest[rest.index("bands") + 1])
 if "shards" in rest:
     kw["shard_count"] = int(rest[rest.index("shards") + 1])
 pt.set_device(0)
