@@ -806,16 +806,22 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // the cuts' price is what keeps the rest of that gain); 2 M triangles under WALK 3840x2160 x64 157.1 / 192.7 / 225.5 (a
     // wave waiting on memory all along pays most for one more wait); RTNW final through the reference's tree under REFILL
     // x64 163.0 / 158.7 / 158.0, x256 639.4 / - / - / 626.6; random spheres over the flat list under REFILL x16 90.4 / 77.4
-    // (a list walk is uniform over the wave and long: the cut is cheap beside it).  So: REFILL up to 8 chunks of at least 4
-    // samples, WALK 4 chunks of at least 32 samples and none with triangles, only for shards of more than one and a half
+    // (a list walk is uniform over the wave and long: the cut is cheap beside it).  Those were measured with one slot counter
+    // for the whole GPU, and much of a cut's price was the wait for that word: with a counter per XCD (slot_band_draw) the
+    // same sweeps read, uncut / 4 / 8 / 16 / 32 chunks: random spheres under WALK x256 139.2 / 128.6 / 132.3 / 138.0 / 143.0,
+    // x1024 550.9 / 501.3 / 496.5 / 506.9 / 521.8; 2 M triangles x64 uncut / 2 / 4 151.9 / 149.0 / 147.8; final through the
+    // reference's tree under REFILL x64 149.8 / 149.2 / 149.8 / 148.4 / 143.4; random spheres over the flat list x64 246.6 /
+    // 209.3 / 201.8 / 199.4 / 195.1.  So: REFILL up to 32 chunks of at least 2 samples; WALK 4 chunks of at least 32 samples
+    // (8 of at least 64 from 512 samples on), with triangles 4 of at least 16; only for shards of more than one and a half
     // sweeps of the GPU's lanes.  chunk_samples: 0 the library's choice, >= ns no chunks.
     if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill != 0 && ra.n_wave_tiles > 0 && !no_alloc && p->ns >= 2) {
         const long long lanes = 256LL * 4 * 64 * 6, slots = (long long)ra.n_wave_tiles * 64;
         int pieces = 1;
         if (p->chunk_samples > 0) pieces = (p->ns + p->chunk_samples - 1) / p->chunk_samples;
         else if (2 * slots > 3 * lanes) {
-            if (ra.refill == 1) pieces = std::min(8, p->ns / 4);
-            else if (!(sc->mask & ptd::F_TRIANGLE)) pieces = std::min(4, p->ns / 32);
+            if (ra.refill == 1) pieces = std::min(32, p->ns / 2);
+            else if (sc->mask & ptd::F_TRIANGLE) pieces = std::min(4, p->ns / 16);
+            else pieces = p->ns >= 512 ? std::min(8, p->ns / 64) : std::min(4, p->ns / 32);
         }
         pieces = (int)std::min<long long>(pieces, 0xffffffffLL / slots);      // slots are numbered in 32 bits
         if (pieces >= 2) {
