@@ -811,7 +811,11 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // same sweeps read, uncut / 4 / 8 / 16 / 32 chunks: random spheres under WALK x256 139.2 / 128.6 / 132.3 / 138.0 / 143.0,
     // x1024 550.9 / 501.3 / 496.5 / 506.9 / 521.8; 2 M triangles x64 uncut / 2 / 4 151.9 / 149.0 / 147.8; final through the
     // reference's tree under REFILL x64 149.8 / 149.2 / 149.8 / 148.4 / 143.4; random spheres over the flat list x64 246.6 /
-    // 209.3 / 201.8 / 199.4 / 195.1.  So: REFILL up to 32 chunks of at least 2 samples; WALK 4 chunks of at least 32 samples
+    // 209.3 / 201.8 / 199.4 / 195.1, and in chunks of one sample 133.3 and 194.7 (final x256: 8 chunks 578.9, chunks of 2
+    // samples 571.3, of one 530.8): a lane that draws a slot per sample traces neighbouring pixels beside its wave's other
+    // lanes all along, not only at the start of the launch, and the walk of the reference's tree diverges less.  (Only where
+    // a sample is long: the rectangle scene under REFILL takes 108 ms in chunks of 8 and 124 in chunks of one against 28 as
+    // chunked tiles.)  So: REFILL in chunks of one sample; WALK 4 chunks of at least 32 samples
     // (8 of at least 64 from 512 samples on), with triangles 4 of at least 16; only for shards of more than one and a half
     // sweeps of the GPU's lanes.  chunk_samples: 0 the library's choice, >= ns no chunks.
     if (p->pipeline != PT_PIPELINE_WAVEFRONT && ra.refill != 0 && ra.n_wave_tiles > 0 && !no_alloc && p->ns >= 2) {
@@ -819,7 +823,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
         int pieces = 1;
         if (p->chunk_samples > 0) pieces = (p->ns + p->chunk_samples - 1) / p->chunk_samples;
         else if (2 * slots > 3 * lanes) {
-            if (ra.refill == 1) pieces = std::min(32, p->ns / 2);
+            if (ra.refill == 1) pieces = p->ns;
             else if (sc->mask & ptd::F_TRIANGLE) pieces = std::min(4, p->ns / 16);
             else pieces = p->ns >= 512 ? std::min(8, p->ns / 64) : std::min(4, p->ns / 32);
         }

@@ -1277,12 +1277,12 @@ def test_persistent_lane_schedules_in_chunks_bit_exact(oracle, which):
     ref = oracle.render(d, 72, 40, 7, shard_index=1, shard_count=3)
     assert_bit_exact(sc.render(72, 40, 7, schedule=schedules[0], chunk_samples=2, shard_index=1, shard_count=3), ref, which + " shard in chunks")
     # more than one and a half times as many pixels as the GPU has lanes (6 waves on each of 1024 SIMDs): the library
-    # cuts by itself -- REFILL into up to 32 chunks of at least 2 samples, WALK into 4 of at least 32 (with triangles, of at least 16)
+    # cuts by itself -- REFILL into chunks of one sample, WALK into 4 of at least 32 (with triangles, of at least 16)
     nx, ny, ns = 1024, 640, 128 if schedules[0] == abi.SCHEDULE_WALK else 32
     whole = sc.render(nx, ny, ns, schedule=schedules[0], chunk_samples=ns)
     assert sc.stats().n_chunks == 0
     cut = sc.render(nx, ny, ns, schedule=schedules[0])
-    assert sc.stats().n_chunks == (4 if schedules[0] == abi.SCHEDULE_WALK else 16)
+    assert sc.stats().n_chunks == (4 if schedules[0] == abi.SCHEDULE_WALK else ns)
     assert_bit_exact(cut, whole, which + " %dx%dx%d, the library's cuts" % (nx, ny, ns))
     assert_bit_exact(sc.render(nx, ny, ns, schedule=schedules[0], chunk_samples=5), whole, which + " %dx%dx%d in chunks of 5" % (nx, ny, ns))
 
