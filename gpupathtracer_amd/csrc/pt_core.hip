@@ -280,7 +280,7 @@ bool signature_faces(const PtSceneDesc* d, std::vector<float>* out)
 
 // ---- host side of the C ABI --------------------------------------------------------------------------
 
-// Scratch of pt_render_device_noalloc: the pixel-slot counter of the persistent-lane schedules in
+// Scratch of pt_render_device_noalloc: the pixel-slot counters of the persistent-lane schedules (eight words, one per XCD) in
 // device memory that exists from the moment the library's code object is loaded, so the call needs
 // no hipMalloc.  One copy per GPU; every such call on a GPU uses that GPU's copy.  In host code the
 // array's name is only a handle for hipGetSymbolAddress: g_scratch_ptr[] holds the device addresses.
@@ -841,7 +841,13 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // 139.2 -> 127.2.
     ra.slot_bands = p->slot_block_tiles < 0 ? 1 : 8;
     ra.band_block_tiles = p->slot_block_tiles > 0 ? p->slot_block_tiles : 64;
-    ra.walk_wait = 48;                  // 32 / 40 / 48 / 56 / 62 of 64 lanes: sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7
+    // Lanes with a finished search that make a wave leave the shared walk's search loop.  32 / 40 / 48 / 56 / 62 of 64 lanes, round 2:
+    // sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7.  Swept again with the slot
+    // counters per XCD (the waves no longer wait for their slots, the balance between walking and shading lanes moved): 2 M
+    // triangles 3840x2160 x64 at 16 / 24 / 32 / 36 / 40 / 44 / 48 / 56 = 155.4 / 141.1 / 136.0 / 133.8 / 135.6 / 138.9 / 147.8 / 197.9 ms
+    // (leaf vote 8; 12 and 6 within 2 %), x16 42.5 / 39.7 / 37.5 / 37.5 / - / 38.6 / 40.4; sphere scene x256 at 40 / 48 / 56 = 133.7 /
+    // 129.1 / 130.6; meshes of 20 000 and 1 800 triangles at 32 / 40 / 48 = 39.0 / 38.5 / 36.5 and 30.1 / 28.5 / 28.1.
+    ra.walk_wait = ((sc->mask & ptd::F_TRIANGLE) && sc->n_shapes >= 100000) ? 36 : 48;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     float* out = static_cast<float*>(d_out_rgb);
     // A stream under graph capture records the work, it does not run it: the scene's timing events stay out of the

@@ -113,7 +113,7 @@ enum PtSchedule {
                              * few tiles for the GPU and many samples), REFILL for reference BVHs walked as
                              * they are and for lists of more than 16 objects                                   */
     PT_SCHEDULE_TILES  = 1, /* one 8x8 tile per wave, one pixel per lane                                 */
-    PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter.  When the shard holds
+    PT_SCHEDULE_REFILL = 2, /* persistent lanes pull the next pixel from a device counter (one per XCD).  When the shard holds
                              * more pixels than the GPU has lanes, REFILL and WALK hand out (chunk of samples, pixel)
                              * pairs instead of pixels, chunk by chunk, so that the launch does not end pixel by
                              * pixel: the pixel's random stream and running sum wait in device memory between its
@@ -330,15 +330,15 @@ int  pt_render_device(PtScene* scene, const PtRenderParams* params, void* d_out_
  * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
  * Same arguments, same frame bit for bit; the call itself performs no hipMalloc / hipFree.  The
  * one piece of device memory the fused pipeline needs beyond the scene and the frame -- the 32-bit
- * pixel-slot counter of the persistent-lane schedules (PT_SCHEDULE_REFILL / _WALK) -- lives in a
- * 256-byte array that is part of the library's device code, one copy per GPU, instead of in memory
- * the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its lane state:
+ * pixel-slot counters of the persistent-lane schedules (PT_SCHEDULE_REFILL / _WALK; eight words, one
+ * per XCD, see PtRenderParams.slot_block_tiles) -- lives in a 256-byte array that is part of the
+ * library's device code, one copy per GPU, instead of in memory the scene allocated.  Limits: the fused pipeline only (PT_PIPELINE_WAVEFRONT allocates its lane state:
  * PT_ERR_UNSUPPORTED); PT_SCHEDULE_CHUNKS, which keeps per-tile state in memory the scene allocates, only when an
  * earlier pt_render_device call has left the scene that memory for a shard at least as large (then PT_SCHEDULE_AUTO
  * picks it here as it does there; without it AUTO runs the tiles whole and asking for CHUNKS is PT_ERR_UNSUPPORTED);
  * REFILL and WALK uncut; at most PT_NOALLOC_MAX_WAVE_TILES 8x8 wave tiles in the shard, so that the
- * counter can number its pixel slots (PT_ERR_INVALID beyond); the scene's device must be current.
- * The counter is cleared at the start of every call.  All calls on one GPU share that GPU's
+ * counters can number its pixel slots (PT_ERR_INVALID beyond); the scene's device must be current.
+ * The counters are cleared at the start of every call.  All calls on one GPU share that GPU's
  * array, whatever the scene or stream: calls that overlap on one GPU race on it and trace pixels
  * twice or not at all -- run them one after another (one stream, or events between streams). */
 #define PT_NOALLOC_MAX_WAVE_TILES (1 << 25)
