@@ -59,6 +59,13 @@ __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
 #endif
     const uint32_t G = F & ~F_LBVH4;                       // the form of the tree does not change the table
     if (F == M_FINAL_LBVH4) return 6;                       // the final scene through the 4-wide tree: 3 / 4 / 5 / 6 = 59.7 / 57.0 / 56.4 / 53.6 ms (1920x1080 x64)
+    // The final scene's kernels wanted registers (3 workgroups) while the rows of the log tables sat in them (pt_libm.h); with
+    // those gone the kernel that walks the reference's BVH needs 134 and prefers waves: 3 / 4 / 5 / 6 workgroups = 132.8 / 108.7 /
+    // 98.7 / 105.8 ms (1920x1080 x64, REFILL in chunks of one sample; 0 / 0 / 43 / 63 spilled registers), through the binary tree
+    // 49.7 / 50.6 / 47.2 / 47.1.  The all-features kernel over the 4-wide tree (no cap before: 1): the rectangle scene asked into
+    // the tree 1024^2 x64 at 1 / 4 / 5 / 6 = 29.3 / 24.4 / 24.0 / 27.2, simple_light 10.4 / 9.2 / 9.9 / 12.6.
+    if (G == M_FINAL || G == M_FINAL_LBVH) return 5;
+    if (F == M_ALL_LBVH4) return 4;
     return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 6 : 1;
 }
 

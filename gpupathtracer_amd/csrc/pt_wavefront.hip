@@ -279,7 +279,11 @@ __host__ __device__ constexpr int wf_min_blocks(uint32_t F)
 #ifdef PT_WF_BLOCKS             // kernel experiments
     return PT_WF_BLOCKS;
 #endif
-    return ((F & ~ptk::M_CORNELL) == 0 || (F & ~F_LBVH4) == ptk::M_TRIMESH) ? 5 : 4;     // 2 M triangles through the 4-wide tree x16: 4 / 5 / 6 = 188 / 147 / 177 ms
+    // 2 M triangles through the 4-wide tree x16: 4 / 5 / 6 = 188 / 147 / 177 ms.  Re-measured once the log tables' rows had left the
+    // registers (pt_libm.h), 4 / 5 / 6: random spheres over the flat list 1920x1080 x16 104.2 / 85.2 / 97.8, final over its list with
+    // the reference's BVH x64 183.1 / 175.3 / 202.2; through the trees no change (spheres x64 55.7 / 56.2 / 55.7, final 67.5 / 68.6 / 72.3).
+    if (F == ptk::M_SPHERES || F == ptk::M_FINAL) return 5;
+    return ((F & ~ptk::M_CORNELL) == 0 || (F & ~F_LBVH4) == ptk::M_TRIMESH) ? 5 : 4;
 }
 // One workgroup renders one group of lanes, round by round.  Every loop bound below is read from
 // LDS after a barrier, so all lanes of the workgroup take the same trips and meet at every barrier.
