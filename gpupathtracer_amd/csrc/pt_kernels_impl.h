@@ -64,9 +64,10 @@ __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
     // 98.7 / 105.8 ms (1920x1080 x64, REFILL in chunks of one sample; 0 / 0 / 43 / 63 spilled registers), through the binary tree
     // 49.7 / 50.6 / 47.2 / 47.1.  The all-features kernel over the 4-wide tree (no cap before: 1): the rectangle scene asked into
     // the tree 1024^2 x64 at 1 / 4 / 5 / 6 = 29.3 / 24.4 / 24.0 / 27.2, simple_light 10.4 / 9.2 / 9.9 / 12.6.
+    // The sphere scene over its flat list, 4 / 5 / 6 / 8: 221.2 / 194.6 / 184.2 / 209.3 ms (1920x1080 x64), simple_spheres 8.21 / 8.12 / 7.90 / 10.70.
     if (G == M_FINAL || G == M_FINAL_LBVH) return 5;
     if (F == M_ALL_LBVH4) return 4;
-    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 5 : (G == M_TRIMESH) ? 6 : 1;
+    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 6 : (G == M_TRIMESH) ? 6 : 1;
 }
 
 // Signature worlds shade from the face table (shade_sig): every workgroup keeps a copy in LDS, 64 bytes

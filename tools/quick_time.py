@@ -38,5 +38,5 @@ for _ in range(3):
     pt.synchronize()
     ms.append(sc.stats().kernel_ms)
 st = sc.stats()
-print("%s %dx%dx%d %s: %.3f ms  %.0f Mpaths/s  (schedule %d, chunks %d, signature %d, all %s)" %
-      (name, nx, ny, spp, " ".join(rest), min(ms), st.paths / min(ms) / 1e3, st.schedule, st.n_chunks, st.signature_walk, ["%.2f" % m for m in ms]), flush=True)
+print("%s %dx%dx%d %s: %.3f ms  %.0f Mpaths/s  (schedule %d, chunks %d, signature %d, family %d, all %s)" %
+      (name, nx, ny, spp, " ".join(rest), min(ms), st.paths / min(ms) / 1e3, st.schedule, st.n_chunks, st.signature_walk, st.kernel_family, ["%.2f" % m for m in ms]), flush=True)

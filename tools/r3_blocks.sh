@@ -1,20 +1,13 @@
 #!/bin/bash
-# Staged kernels at their table's workgroups per CU (tree build) / 5 / 6 everywhere, same box.
+# All-features kernels over lists and the binary tree at 3 (tree build) / 4 / 5 workgroups per CU, same box.
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }
-for lib in "" tools/exp/libptcore_w5.so tools/exp/libptcore_w6.so; do
+for lib in "" tools/exp/libptcore_a4.so tools/exp/libptcore_a5.so; do
   export PT_LIBPTCORE_PATH=$lib
   [ -z "$lib" ] && unset PT_LIBPTCORE_PATH
   echo "== lib: ${lib:-tree}"
-  q random 1920 1080 64 lbvh wavefront
-  q final 1920 1080 64 lbvh wavefront
-  q final 1920 1080 64 wavefront
-  q random 1920 1080 16 wavefront
-  q cornell 1024 1024 512 wavefront
-  q trimesh1000 3840 2160 16 lbvh wavefront
+  q simple_light 1024 512 256
+  q cornell_spheres 1024 1024 64
+  q cornell 1024 1024 64 binary
 done
-echo "== fused, final and all-features kernels at their new caps"
-q final 1920 1080 256
-q final 1920 1080 64 binary
-q cornell 1024 1024 64 lbvh
