@@ -67,7 +67,9 @@ __host__ __device__ constexpr int fused_min_blocks(uint32_t F)
     // The sphere scene over its flat list, 4 / 5 / 6 / 8: 221.2 / 194.6 / 184.2 / 209.3 ms (1920x1080 x64), simple_spheres 8.21 / 8.12 / 7.90 / 10.70.
     if (G == M_FINAL || G == M_FINAL_LBVH) return 5;
     if (F == M_ALL_LBVH4) return 4;
-    return (G & F_REFBVH) ? 3 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 6 : (G == M_TRIMESH) ? 6 : 1;
+    // The all-features kernels over lists and the binary tree, 3 / 4 / 5: simple_light 1024x512 x256 28.3 / 24.9 / 26.3 ms, the rectangle
+    // scene asked into the binary tree 1024^2 x64 26.0 / 21.7 / 22.3.
+    return (G & F_REFBVH) ? 4 : (G == M_CORNELL) ? 6 : (G == M_SPHERES_LBVH) ? 6 : (G == M_SPHERES) ? 6 : (G == M_TRIMESH) ? 6 : 1;
 }
 
 // Signature worlds shade from the face table (shade_sig): every workgroup keeps a copy in LDS, 64 bytes
