@@ -3,7 +3,11 @@
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }
-q trimesh1000 3840 2160 64 lbvh
-q trimesh1000 3840 2160 16 lbvh
-q trimesh100 1920 1080 64 lbvh
+q random 1920 1080 256 lbvh
 q random 1920 1080 1024 lbvh
+q random 1920 1080 64
+q cornell_spheres 1024 1024 64
+q simple_spheres 1024 512 256
+q final 1920 1080 256 lbvh
+q final 1920 1080 64
+q random 1920 1080 64 lbvh wavefront
