@@ -81,7 +81,7 @@ def test_thin_lens_through_progressive_passes_and_shards(oracle):
     assert_bit_exact(acc, ref, "shards")
 
 
-def _uv_lab(order, accel, moving_y=0.2):
+def _uv_lab(order, accel, moving_y=0.2, boundary="sphere"):
     """A room small enough that a MovingSphere's world-space hit point has |y| < 1 (its uv is then
     finite: get_uv takes asinf of the un-normalised point): an image-textured floor, a lamp, a moving
     sphere, a plain sphere and a smoke ball, all reading one image; `order` permutes the world list,
@@ -111,7 +111,9 @@ def _uv_lab(order, accel, moving_y=0.2):
               shape(abi.SHAPE_RECT_XZ, [-1, 1, -1, 1, 2.5], light_img, flags=abi.FLIP_NORMAL),  # 1 lamp, emits the image
               shape(abi.SHAPE_MOVING_SPHERE, [0, 0, 0, 0, moving_y, 0, 0, 1, 0.7], lam_img),  # 2 moving sphere: uv from atan2f/asinf
               shape(abi.SHAPE_SPHERE, [1.3, -0.3, 0.4, 0.5], lam_chk),                         # 3 plain sphere: stale uv through a checker of the image
-              shape(abi.SHAPE_SPHERE, [-1.3, -0.2, 0.3, 0.6], lam_img),                        # 4 boundary of the smoke ball
+              {"sphere": shape(abi.SHAPE_SPHERE, [-1.3, -0.2, 0.3, 0.6], lam_img),             # 4 boundary of the smoke ball
+               "box": shape(abi.SHAPE_BOX, [-1.9, -0.8, -0.3, -0.7, 0.4, 0.9], lam_img),       #   ... or of a smoke box (the reference's cornell_smoke)
+               "moving": shape(abi.SHAPE_MOVING_SPHERE, [-1.3, -0.2, 0.3, -1.2, 0.1, 0.3, 0, 1, 0.6], lam_img)}[boundary],
               shape(abi.SHAPE_RECT_XY, [-3, 3, -0.9, 2.5, -2.5], lam_chk),                     # 5 back wall
               shape(abi.SHAPE_RECT_XZ, [-1, 1, -1, 1, 2.5], -1)]                               # 6 the light shape
     g.lists["shapes"] = shapes
@@ -147,6 +149,28 @@ def test_moving_sphere_and_medium_uv_under_an_image_texture(oracle, order):
             assert np.unique(moving[:, 7]).size > 50
             assert (ids == abi.ID_MEDIUM_BASE).sum() > 20                         # the smoke is hit
         what = "uv lab %s accel %d" % ("/".join(order), accel)
+        for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
+            assert_bit_exact(sc.render(96, 54, 6, schedule=schedule), ref, what + " schedule %d" % schedule)
+        assert_bit_exact(sc.render(96, 54, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, what + " staged")
+        assert_same_hits(oracle, g, sc, rays, what)
+
+
+@pytest.mark.parametrize("boundary", ["box", "moving"])
+def test_medium_inside_other_boundaries(oracle, boundary):
+    """ConstantMedium::hit (include/ptMedium.h:31-55) searches its boundary twice, whatever the boundary is: a box (six
+    rectangle tests each time) and a moving sphere take the general path, a plain sphere the one that forms its
+    quadratic once.  Frames and closest hits against the oracle, list and tree, every scheduler."""
+    order = UV_ORDERS[1]
+    ref = None
+    for accel in (abi.ACCEL_LIST, abi.ACCEL_LBVH):
+        g = _uv_lab(order, accel, boundary=boundary)
+        sc = pt.Scene(g)
+        if ref is None:
+            ref = oracle.render(g, 96, 54, 6)
+            rays = oracle.record_rays(g, 48, 27, 8, 40000)
+            ids, _ = oracle.trace_records(g, rays)
+            assert (ids == abi.ID_MEDIUM_BASE).sum() > 20                         # the smoke is hit
+        what = "smoke inside a %s, accel %d" % (boundary, accel)
         for schedule in (abi.SCHEDULE_AUTO, abi.SCHEDULE_TILES, abi.SCHEDULE_REFILL):
             assert_bit_exact(sc.render(96, 54, 6, schedule=schedule), ref, what + " schedule %d" % schedule)
         assert_bit_exact(sc.render(96, 54, 6, pipeline=abi.PIPELINE_WAVEFRONT), ref, what + " staged")
