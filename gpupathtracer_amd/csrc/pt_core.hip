@@ -841,7 +841,7 @@ static int render_device(PtScene* sc, const PtRenderParams* p, void* d_out_rgb, 
     // 139.2 -> 127.2.
     ra.slot_bands = p->slot_block_tiles < 0 ? 1 : 8;
     ra.band_block_tiles = p->slot_block_tiles > 0 ? p->slot_block_tiles : 64;
-    // Lanes with a finished search that make a wave leave the shared walk's search loop.  32 / 40 / 48 / 56 / 62 of 64 lanes, round 2:
+    // Lanes with a finished search that make a wave leave the shared walk's search loop.  32 / 40 / 48 / 56 / 62 of 64 lanes, first sweep:
     // sphere scene 38.2 / 36.1 / 35.6 / 35.6 / 36.4 ms, triangle field 35.1 / 31.2 / 28.8 / 29.1 / 42.7.  Swept again with the slot
     // counters per XCD (the waves no longer wait for their slots, the balance between walking and shading lanes moved): 2 M
     // triangles 3840x2160 x64 at 16 / 24 / 32 / 36 / 40 / 44 / 48 / 56 = 155.4 / 141.1 / 136.0 / 133.8 / 135.6 / 138.9 / 147.8 / 197.9 ms

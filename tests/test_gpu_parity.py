@@ -1726,7 +1726,7 @@ def test_random_worlds_of_the_final_scenes_kinds_match_the_oracle(oracle, seed):
 
 # World 100401 is kept by name: a ray of its frame grazes a box of the reference BVH whose leaves sit in the library's tree,
 # the reference's own walk turns it away at the box, and the shared-walk schedule (which AUTO takes there: the world holds
-# triangles) once kept the leaf -- found by the round-3 campaign, 1 world in 4 000.
+# triangles) once kept the leaf -- found by a long fuzz campaign, 1 world in 4 000.
 @pytest.mark.parametrize("seed", list(range(FUZZ_FIRST, FUZZ_FIRST + int(os.environ.get("PT_FUZZ_TEXTURED_WORLDS", "16")))) + ([100401] if FUZZ_FIRST == 0 else []))
 def test_random_textured_worlds_through_a_lens_match_the_oracle(oracle, seed):
     """The random worlds again with image, noise and (nested) checker textures on their Lambertian,

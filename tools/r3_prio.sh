@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 measurement: CHUNKS with and without cost-based wave priority, against TILES, on the whole frame and on shards.
+# Measurement: CHUNKS with and without cost-based wave priority, against TILES, on the whole frame and on shards.
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 standard timing set (kernel ms, best of three): the four benchmark configurations at reduced sample counts.
+# Standard timing set (kernel ms, best of three): the four benchmark configurations at reduced sample counts.
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }

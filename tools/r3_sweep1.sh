@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 measurement: the persistent-lane schedules with and without chunks of samples.
+# Measurement: the persistent-lane schedules with and without chunks of samples.
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }
