@@ -692,6 +692,7 @@ bool make_args(const PtRenderParams* p, RenderArgs* ra)
     ra->seed_offset = (uint64_t)p->batch_index * (uint64_t)p->nx * (uint64_t)p->ny;
     ra->raw_sum = p->raw_sum ? 1 : 0;
     ra->stage_stats = p->stage_stats ? 1 : 0;
+    ra->wf_chunk_samples = p->chunk_samples > 0 ? p->chunk_samples : 0;
     return true;
 }
 

@@ -25,6 +25,7 @@ struct RenderArgs {
     uint64_t seed_offset;          // added to the pixel index before seeding (sample batches; 0 = the reference's stream)
     int32_t chunk_samples, n_chunks;   // chunked tiles: samples per work item and items per tile (0: not chunked)
     int32_t stage_stats;           // staged scheduler: count what the stages did
+    int32_t wf_chunk_samples;      // staged scheduler: PtRenderParams.chunk_samples as the caller gave it (0: the library's choice)
     int32_t chunk_priority;        // chunked tiles: later chunks of expensive tiles run at a raised wave priority
 };
 

@@ -60,6 +60,10 @@ struct WfState {
     unsigned long long* stats;    // PtStageStats as 16 counters, summed over the launch's workgroups (see k_wf_groups)
     int32_t   group_lanes;    // lanes per group: a multiple of 256, at most WF_GROUP_MAX
     int32_t   round_limit;    // rounds after which a group gives up (a lane was lost: cannot happen, must not hang)
+    int32_t   ns_end;         // the sample count at which a lane's work ends: the pixel's last sample, or the end of a chunk (k_wf_chunks)
+    int32_t   chunk_samples, n_chunks;    // k_wf_chunks: samples per work item, items per group
+    unsigned* words;          // k_wf_chunks: [0] the ticket, [4 ..) a progress word per group
+    unsigned long long* group_states;     // k_wf_chunks: a group's random-stream states and running sums between its chunks (WF_GROUP_STATE_WORDS each)
 };
 
 // The material queues a feature mask can fill.
@@ -113,18 +117,27 @@ template <uint32_t F, int... K> struct WfFaces<F, WorldSig<K...>> {
 // The path of lane l ended with running product thr: accumulate it (deNan, src/ptMain.cu:46-53,161)
 // and start the pixel's next sample (src/ptMain.cu:156-160), or write the pixel when it was the last.
 // Returns true when a fresh camera ray was stored and the lane must go to the next extend stage.
+// `begin`: no path has ended, the lane starts its work item at sample s (nothing is accumulated first).  A lane whose
+// item ends before the pixel's last sample (w.ns_end < ra.ns: a chunk) leaves its sum where the item's end collects it.
 __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& ra, const WfState& w, uint32_t l, uint32_t i,
-                                         V3 acc, int s, V3 thr, Pcg& rng, float* __restrict__ out)
+                                         V3 acc, int s, V3 thr, Pcg& rng, float* __restrict__ out, bool begin = false)
 {
     const int x = (int)(i % (uint32_t)ra.nx), ytop = (int)(i / (uint32_t)ra.nx);
     const int y = ra.ny - 1 - ytop;
     while (true) {
-        if (!(thr.x == thr.x)) thr.x = 0;
-        if (!(thr.y == thr.y)) thr.y = 0;
-        if (!(thr.z == thr.z)) thr.z = 0;
-        acc = acc + thr;
-        s++;
-        if (s >= ra.ns) {
+        if (!begin) {
+            if (!(thr.x == thr.x)) thr.x = 0;
+            if (!(thr.y == thr.y)) thr.y = 0;
+            if (!(thr.z == thr.z)) thr.z = 0;
+            acc = acc + thr;
+            s++;
+        }
+        begin = false;
+        if (s >= w.ns_end) {
+            if (w.ns_end < ra.ns) {
+                w.acc[l] = make_float4(acc.x, acc.y, acc.z, __int_as_float(s));
+                return false;
+            }
             const float inv_ns = 1 / (float)ra.ns;
             out[3 * (size_t)i + 0] = sqrtf(fmaxf(0.0f, acc.x * inv_ns));
             out[3 * (size_t)i + 1] = sqrtf(fmaxf(0.0f, acc.y * inv_ns));
@@ -323,9 +336,7 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
             w.pix[l] = i;
             Pcg rng;
             rng.seed(i);
-            // "end" a virtual empty path whose contribution is exactly zero: the sum stays 0 + 0, and the
-            // sample count goes from -1 to 0
-            go = end_path(sv, ra, w, l, i, mk(0, 0, 0), -1, mk(0, 0, 0), rng, out);
+            go = end_path(sv, ra, w, l, i, mk(0, 0, 0), 0, mk(0, 0, 0), rng, out, true);
             w.rng[l] = rng.state;
         }
         queue_push(gq.ext[0], &gq.n_ext[0], live && go, j);
@@ -372,6 +383,123 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
     }
 }
 
+
+// k_wf_groups with every group's samples cut into chunks, for frames of few groups and many samples (the headline:
+// 4 096 groups of 4 096 samples for 1 280 resident workgroups, 3.2 rounds: the launch ends with most of the GPU idle
+// behind its last groups, and the same paths traced as a 4096^2 frame at 256 samples take 287 ms against 348).  The
+// work item is (chunk, group), numbered chunk-major; persistent workgroups draw item numbers from a counter, so items
+// start in order.  A pixel's samples stay one sequence (src/ptMain.cu:156-162): between chunks the lanes' random-stream
+// states and running sums wait in `group_states` (WF_GROUP_STATE_WORDS 64-bit words a group: 256 states, then the sums'
+// three components as rows of 256 floats), and chunk c of a group starts once the group's progress word says chunk
+// c - 1 has been stored.  The wait cannot deadlock (the item waited for has a smaller number, so a running workgroup
+// holds it, and chains of waits end at a chunk 0) and is bounded by progress all the same: a word that stands still
+// for 2^23 polls raises *w.lost = 2.  Only for kernels that keep their lanes in LDS (lanes_in_lds).
+// The loop keeps the shape of k_render_chunks' (one errand of thread 0 per round, between two barriers): see there.
+constexpr int WF_GROUP_STATE_WORDS = WF_GROUP_LDS + 3 * (WF_GROUP_LDS / 2);      // 5 120 bytes
+template <uint32_t F, class W>
+__global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
+{
+    static_assert(lanes_in_lds<F>::value, "the chunked staged kernel keeps its lanes in LDS");
+    constexpr int NQ = ShadeQueues<F>::value;
+    __shared__ float4 faces[WfFaces<F, W>::float4s];
+    __shared__ GroupQueues<NQ> gq;
+    __shared__ LdsLanes<true> lanes;
+    __shared__ unsigned s_item;
+    unsigned* const words = w.words;
+    unsigned long long* const group_states = w.group_states;
+    const int n_chunks = w.n_chunks, chunk_samples = w.chunk_samples;
+    w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit = lanes.hit;
+    w.rng = lanes.rng; w.pix = lanes.pix;
+    if constexpr (WfFaces<F, W>::used) {
+        for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) { const float* f = sv.sig_faces + 4 * k; faces[k] = make_float4(f[0], f[1], f[2], f[3]); }
+    }
+    const unsigned groups = ((unsigned)ra.n_wave_tiles * 64u + (unsigned)WF_GROUP_LDS - 1u) / (unsigned)WF_GROUP_LDS;
+    const unsigned n_items = groups * (unsigned)n_chunks;
+    unsigned* const progress = words + 4;
+    bool finished_one = false;
+    unsigned finished_grp = 0, finished_c = 0;
+    while (true) {
+        if (threadIdx.x == 0) {
+            if (finished_one) __hip_atomic_store(&progress[finished_grp], finished_c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = atomicAdd(&words[0], 1u);
+        }
+        if (threadIdx.x < 2) gq.n_ext[threadIdx.x] = 0;
+        if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (item >= n_items) break;
+        const int c = (int)(item / groups);
+        const unsigned grp = item - (unsigned)c * groups;
+        if (c > 0) {
+            if (threadIdx.x == 0) {
+                unsigned spins = 0, seen = 0;
+                while (true) {                                    // relaxed polls, one acquire fence below (as k_render_chunks)
+                    const unsigned now = __hip_atomic_load(&progress[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (now >= (unsigned)c) break;
+                    if (now != seen) { seen = now; spins = 0; }
+                    __builtin_amdgcn_s_sleep(64);
+                    if (++spins > (1u << 23)) { *w.lost = 2; break; }
+                }
+            }
+            __syncthreads();
+            __threadfence();                                      // every wave: the loads below come after the word
+        }
+        w.ns_end = min(ra.ns, (c + 1) * chunk_samples);
+        const uint32_t group_first = grp * (uint32_t)WF_GROUP_LDS;
+        unsigned long long* const st_rng = group_states + (size_t)grp * WF_GROUP_STATE_WORDS;
+        float* const st_sum = reinterpret_cast<float*>(st_rng + WF_GROUP_LDS);
+        // generate: this workgroup's thread j is the group's lane j
+        {
+            const uint32_t j = threadIdx.x;
+            const int wave = (int)((group_first + j) >> 6), lane = (int)(j & 63);
+            int x = 0, ytop = 0;
+            const bool live = wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop);
+            bool go = false;
+            if (live) {
+                const unsigned i = (unsigned)(ytop * ra.nx + x);
+                w.pix[j] = i;
+                Pcg rng;
+                rng.seed(i);
+                V3 acc = mk(0, 0, 0);
+                if (c > 0) {
+                    rng.state = st_rng[j];
+                    acc = mk(st_sum[j], st_sum[WF_GROUP_LDS + j], st_sum[2 * WF_GROUP_LDS + j]);
+                }
+                go = end_path(sv, ra, w, j, i, acc, c * chunk_samples, mk(0, 0, 0), rng, out, true);
+                w.rng[j] = rng.state;
+            }
+            queue_push(gq.ext[0], &gq.n_ext[0], live && go, j);
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int round = 0; ; round++) {
+            if (gq.n_ext[cur] == 0) break;                          // every lane of the group has reached the item's last sample
+            if (round >= w.round_limit) { if (threadIdx.x == 0) *w.lost = 1; break; }
+            extend_stage<F, W, false>(sv, ra, w, out, nullptr, faces, gq, cur, 0u, nullptr);
+            __syncthreads();
+            for (int q = 0; q < NQ; q++) shade_stage<F, W, false>(sv, ra, w, q, out, faces, gq, cur, 0u, nullptr);
+            __syncthreads();
+            if (threadIdx.x == 0) gq.n_ext[cur] = 0;
+            if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
+            cur ^= 1;
+            __syncthreads();
+        }
+        if (c < n_chunks - 1) {                                     // the lanes' states wait for the group's next chunk
+            const uint32_t j = threadIdx.x;
+            const int wave = (int)((group_first + j) >> 6), lane = (int)(j & 63);
+            int x = 0, ytop = 0;
+            if (wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop)) {
+                const float4 a4 = w.acc[j];
+                st_rng[j] = w.rng[j];
+                st_sum[j] = a4.x; st_sum[WF_GROUP_LDS + j] = a4.y; st_sum[2 * WF_GROUP_LDS + j] = a4.z;
+            }
+        }
+        __threadfence();                                          // every lane's stores before the word
+        __syncthreads();
+        finished_one = true; finished_grp = grp; finished_c = (unsigned)c;
+    }
+}
+
 bool hip_ok2(hipError_t e, const char* what)
 {
     if (e == hipSuccess) return true;
@@ -386,6 +514,23 @@ void launch_groups(const SceneView& sv, const RenderArgs& ra, const WfState& w, 
 {
     if (ra.stage_stats) hipLaunchKernelGGL((k_wf_groups<F, W, true>), dim3(groups), dim3(256), 0, st, sv, ra, w, out);
     else hipLaunchKernelGGL((k_wf_groups<F, W, false>), dim3(groups), dim3(256), 0, st, sv, ra, w, out);
+}
+
+template <uint32_t F, class W>
+void launch_chunks(const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned workgroups, float* out, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_wf_chunks<F, W>), dim3(workgroups), dim3(256), 0, st, sv, ra, w, out);
+}
+// The variants whose kernels keep their lanes in LDS (lanes_in_lds) have a chunked form.
+bool launch_chunks_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned workgroups, float* out, hipStream_t st)
+{
+    using namespace ptk;
+    switch (variant) {
+    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_chunks<M_CORNELL, CornellWorld>(sv, ra, w, workgroups, out, st); return true;
+    case V_CORNELL: launch_chunks<M_CORNELL, AnyWorld>(sv, ra, w, workgroups, out, st); return true;
+    case V_SPHERES: launch_chunks<M_SPHERES, AnyWorld>(sv, ra, w, workgroups, out, st); return true;
+    default: return false;
+    }
 }
 
 // The feature mask of the kernel a scene variant runs on (what launch_variant instantiates): it,
@@ -457,7 +602,24 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
     // frame after frame pays for it once); it grows when a larger shard comes along.
     const bool image = (kernel_mask & F_IMAGE) != 0;      // the kernels compiled with image textures keep the uv field
     const size_t per_lane = 16 * (image ? 6 : 5) + 8 + 4;
-    const size_t bytes = (in_lds ? 0 : (size_t)n_lanes * per_lane) + 256;
+    // Chunks of samples (k_wf_chunks), for the kernels that keep their lanes in LDS: asked for (chunk_samples), or by
+    // itself when the groups are few for the GPU (under two rounds of its resident workgroups the launch ends with its
+    // slowest group either way) and the samples many; about 32 rounds of work items then.  Rectangle scene 1024^2 x4096:
+    // 348 ms whole groups, the same paths as a 4096^2 frame at 256 samples (groups to spare) 287.
+    int pieces = 1;
+    const long long resident = 256LL * wf_min_blocks(kernel_mask);
+    if (in_lds && !ra.stage_stats && ra.ns >= 2 && (sc->variant == ptk::V_CORNELL_WORLD || sc->variant == ptk::V_CORNELL_WORLD_FLAT ||
+                                                      sc->variant == ptk::V_CORNELL || sc->variant == ptk::V_SPHERES)) {
+        if (ra.wf_chunk_samples > 0) pieces = (ra.ns + ra.wf_chunk_samples - 1) / ra.wf_chunk_samples;
+        else if ((long long)groups >= 2 * resident && ra.ns >= 128)
+            pieces = (int)std::min<long long>((32 * resident + groups - 1) / groups, ra.ns / 32);
+        pieces = (int)std::min<long long>(std::max(pieces, 1), 0x7fffffffLL / groups);      // work items are numbered in 32 bits
+    }
+    const int chunk_samples = pieces > 1 ? (ra.ns + pieces - 1) / pieces : ra.ns;
+    if (pieces > 1) pieces = (ra.ns + chunk_samples - 1) / chunk_samples;
+    const size_t states_bytes = pieces > 1 ? (size_t)groups * WF_GROUP_STATE_WORDS * sizeof(unsigned long long) : 0;
+    const size_t words_bytes = pieces > 1 ? (((size_t)4 + groups) * sizeof(unsigned) + 255) / 256 * 256 : 0;
+    const size_t bytes = (in_lds ? 0 : (size_t)n_lanes * per_lane) + 256 + states_bytes + words_bytes;
     if (sc->wf_workspace_bytes < bytes) {
         if (sc->wf_workspace) { (void)hipFree(sc->wf_workspace); sc->wf_workspace = nullptr; sc->wf_workspace_bytes = 0; }
         if (!hip_ok2(hipMalloc(&sc->wf_workspace, bytes), "hipMalloc(wavefront state)")) return PT_ERR_OOM;
@@ -477,6 +639,14 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
         w.pix = reinterpret_cast<uint32_t*>(take((size_t)n_lanes * 4));
     }
     w.lost = reinterpret_cast<int*>(take(256));
+    w.ns_end = ra.ns;
+    w.chunk_samples = chunk_samples; w.n_chunks = pieces;
+    w.words = nullptr; w.group_states = nullptr;
+    if (pieces > 1) {
+        w.group_states = reinterpret_cast<unsigned long long*>(take(states_bytes));
+        w.words = reinterpret_cast<unsigned*>(take(words_bytes));
+        if (!hip_ok2(hipMemsetAsync(w.words, 0, words_bytes, st), "hipMemsetAsync(chunk words)")) return PT_ERR_HIP;
+    }
     w.stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.lost) + 64);
     static_assert(sizeof(PtStageStats) == 16 * sizeof(unsigned long long) && 64 + sizeof(PtStageStats) <= 256, "the flag block holds the stage counters");
     w.group_lanes = group_lanes;
@@ -486,17 +656,24 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
     w.round_limit = (int32_t)std::min<long long>(limit, 0x7fffffff);
     if (!hip_ok2(hipMemsetAsync(w.lost, 0, 256, st), "hipMemsetAsync(flag and stage counters)")) return PT_ERR_HIP;
 
-    launch_variant(sc->variant, sc->view, ra, w, groups, d_out, st);
+    if (pieces > 1) {
+        const unsigned workgroups = (unsigned)std::min<long long>((long long)groups * pieces, resident);     // persistent: they draw work items from the ticket
+        if (!launch_chunks_variant(sc->variant, sc->view, ra, w, workgroups, d_out, st)) { pt::set_error("wavefront: no chunked kernel for this scene"); return PT_ERR_UNSUPPORTED; }
+    } else {
+        launch_variant(sc->variant, sc->view, ra, w, groups, d_out, st);
+    }
     if (!hip_ok2(hipGetLastError(), "wavefront launch")) return PT_ERR_HIP;
     int lost = 0;
     if (!hip_ok2(hipMemcpyAsync(&lost, w.lost, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(flag)")) return PT_ERR_HIP;
     if (ra.stage_stats && !hip_ok2(hipMemcpyAsync(&sc->stage_stats, w.stats, sizeof(PtStageStats), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(stage counters)")) return PT_ERR_HIP;
     if (!hip_ok2(hipStreamSynchronize(st), "wavefront render")) return PT_ERR_HIP;
     if (lost) {
-        pt::set_error("wavefront: a group did not finish within the rounds its sample and bounce counts allow");
+        pt::set_error(lost == 2 ? "wavefront: a group's chunk gave up waiting for the chunk before it; the frame is not valid"
+                                : "wavefront: a group did not finish within the rounds its sample and bounce counts allow");
         return PT_ERR_HIP;
     }
     sc->last.n_launches = 1;
+    sc->last.n_chunks = pieces > 1 ? pieces : 0;
     if (ra.stage_stats) sc->have_stage_stats = true;
     return PT_OK;
 }

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 # k_render_chunks instantiations per translation unit: the rectangle scenes' three (generic walk, compiled-in walk,
 # its branchless form), the sphere scenes' list walk and binary tree in one unit, one each elsewhere
-EXPECTED = {"pt_k_cornell": 3, "pt_k_spheres": 2}
+EXPECTED = {"pt_k_cornell": 3, "pt_k_spheres": 2, "pt_wavefront": 3}      # the staged pipeline's chunk kernel: rectangle scenes (two walks), sphere lists
 
 
 @pytest.fixture(scope="module")
@@ -26,6 +26,7 @@ def assembled(tmp_path_factory):
     out = tmp_path_factory.mktemp("kernel_asm")
     units = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(ROOT, "gpupathtracer_amd", "csrc", "pt_k_*.hip")))
     assert len(units) >= 11
+    units.append("pt_wavefront")
 
     def assemble(unit):
         src = os.path.join(ROOT, "gpupathtracer_amd", "csrc", unit + ".hip")

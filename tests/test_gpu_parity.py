@@ -381,6 +381,48 @@ def test_wavefront_scheduler_bit_exact(oracle, name, aspect, nx, ny, ns):
     assert_bit_exact(img, oracle.render(d, nx, ny, ns), name + " (wavefront)")
 
 
+@pytest.mark.parametrize("which", ["cornell", "cornell_permuted", "random"])
+def test_wavefront_scheduler_in_chunks_bit_exact(oracle, which):
+    """The staged scheduler with every group's samples cut into chunks (k_wf_chunks: persistent workgroups draw (chunk,
+    group) items from a counter, the lanes' random-stream states and running sums wait in device memory between a
+    group's chunks).  Where the cuts fall changes no sample: chunks of one sample, sizes that do not divide the count,
+    bounce limits 0 and 1, a shard, and the library's own cuts on a frame of many groups."""
+    if which == "random":
+        d = pt.builtin_scene("random", 2.0)                       # over its flat list: the sphere kernels keep their lanes in LDS too
+    elif which == "cornell_permuted":                             # the rectangle scene's kinds in another order: the generic walk
+        from tests._desc_tools import OwnedDesc
+        g = OwnedDesc(pt.builtin_scene("cornell", 1.0))
+        g.lists["world"] = list(reversed(g.lists["world"]))
+        d = g.finalize()
+    else:
+        d = pt.builtin_scene("cornell", 1.0)
+    sc = pt.Scene(d)
+    for nx, ny, ns in ((72, 40, 7), (8, 8, 9), (3, 2, 5)):
+        ref = oracle.render(d, nx, ny, ns)
+        for chunk in (1, 2, 3, ns - 1):
+            img = sc.render(nx, ny, ns, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=chunk)
+            assert_bit_exact(img, ref, "%s staged %dx%dx%d in chunks of %d" % (which, nx, ny, ns, chunk))
+            assert sc.stats().n_chunks == (ns + chunk - 1) // chunk and sc.stats().pipeline == abi.PIPELINE_WAVEFRONT
+        assert_bit_exact(sc.render(nx, ny, ns, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=ns), ref, "uncut")
+        assert sc.stats().n_chunks == 0
+    for depth in (0, 1):
+        assert_bit_exact(sc.render(37, 21, 5, depth, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=2), oracle.render(d, 37, 21, 5, depth),
+                         "%s staged in chunks, bounce limit %d" % (which, depth))
+    ref = oracle.render(d, 72, 40, 7, shard_index=1, shard_count=3)
+    assert_bit_exact(sc.render(72, 40, 7, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=2, shard_index=1, shard_count=3), ref, which + " staged shard in chunks")
+    if which != "random":
+        # 4 096 groups for 1 280 resident workgroups and 128 samples: the library cuts by itself (into 4 here)
+        whole = sc.render(1024, 1024, 128, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=128)
+        assert sc.stats().n_chunks == 0
+        cut = sc.render(1024, 1024, 128, pipeline=abi.PIPELINE_WAVEFRONT)
+        assert sc.stats().n_chunks == 4
+        assert_bit_exact(cut, whole, which + " 1024x1024x128 staged, the library's cuts")
+        assert_bit_exact(cut, sc.render(1024, 1024, 128), which + " 1024x1024x128 staged against fused")
+        counted = sc.render(1024, 1024, 128, pipeline=abi.PIPELINE_WAVEFRONT, stage_stats=1)       # the counting kernel runs whole groups
+        assert sc.stats().n_chunks == 0
+        assert_bit_exact(counted, whole, which + " counting kernel")
+
+
 def test_wavefront_scheduler_edge_cases(oracle):
     d = pt.builtin_scene("cornell", 37 / 21)
     sc = pt.Scene(d)

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Structure check of every k_render_chunks specialisation in the compiler's assembly (no GPU needed).
+"""Structure check of every k_render_chunks and k_wf_chunks specialisation in the compiler's assembly (no GPU needed).
 
 The kernel's persistent loop pairs two barriers per round with one ticket draw by thread 0.  A compiler that rearranges
 the loop for thread 0 alone (it did, for a first version of the source) leaves the other lanes circling through the
 barriers on a stale ticket, for ever.  The check: every loop of the kernel that holds an s_barrier also holds the
-ticket's global_atomic_add (the one that returns a value: the cost counters' atomics return nothing).
+ticket's global_atomic_add (the one that returns a value: the cost counters' atomics return nothing).  The staged
+kernel (k_wf_chunks) runs rounds of stages inside a work item, barriers in a loop of their own: there the check is that
+some loop holds both the ticket and a barrier.  For both kernels no loop may hold the ticket without a barrier.
 
 Loops are the natural loops of the kernel's control-flow graph, built from the labels and branches of the assembly:
 a branch to an earlier line is not enough to call something a loop (the compiler lays cold blocks out behind a loop
@@ -114,8 +116,9 @@ def main():
     bad = 0
     for f in sorted(glob.glob((sys.argv[1] if len(sys.argv) > 1 else '/tmp/chk') + '/*.s')):
         txt = open(f).read()
-        for m in re.finditer(r'^(_Z15k_render_chunks\S*):[^\n]*\n(.*?\n\ts_endpgm)', txt, re.S | re.M):
+        for m in re.finditer(r'^(_Z\S*(?:15k_render_chunks|11k_wf_chunks)\S*):[^\n]*\n(.*?\n\ts_endpgm)', txt, re.S | re.M):
             name, body = m.group(1), m.group(2)
+            staged = 'k_wf_chunks' in name          # its work item loops over rounds of stages: barriers in an inner loop of their own
             lines = body.split('\n')
             blocks, succ = blocks_of(lines)
             has_bar = [any(re.match(r'\s+s_barrier', lines[i]) for i in range(s, e + 1)) for s, e in blocks]
@@ -125,9 +128,14 @@ def main():
             if sum(has_ticket) != 1:
                 ok, why = False, 'expected one ticket draw, found %d' % sum(has_ticket)
             for h, members in loops:
-                if any(has_bar[b] for b in members) and not any(has_ticket[b] for b in members):
+                if not staged and any(has_bar[b] for b in members) and not any(has_ticket[b] for b in members):
                     ok = False
                     why = 'the loop headed at line %d holds a barrier but no ticket' % blocks[h][0]
+                if any(has_ticket[b] for b in members) and not any(has_bar[b] for b in members):
+                    ok = False
+                    why = 'the loop headed at line %d holds the ticket but no barrier: thread 0 circles alone' % blocks[h][0]
+            if staged and not any(any(has_ticket[b] for b in members) and any(has_bar[b] for b in members) for _, members in loops):
+                ok, why = False, 'no loop holds both the ticket and a barrier'
             if not any(any(has_bar[b] for b in members) for _, members in loops):
                 ok, why = False, 'no loop holds a barrier'
             dem = subprocess.run(['c++filt', name], stdout=subprocess.PIPE, text=True).stdout.strip()

@@ -1,12 +1,15 @@
 #!/bin/bash
-# What AUTO picks now, timed.
+# The staged pipeline in chunks of samples on the headline frame.
 set -e
 T="timeout -k 10"
-q() { $T 300 python3 tools/quick_time.py "$@"; }
-q random 1920 1080 64
-q random 1920 1080 256 lbvh
-q random 1920 1080 1024 lbvh
-q random 1920 1080 16 wavefront
-q random 1920 1080 64 lbvh wavefront
-q final 1920 1080 256 lbvh
-q final 1920 1080 64
+q() { $T 120 python3 tools/quick_time.py "$@"; }
+q cornell 1024 1024 4096 wavefront
+q cornell 1024 1024 4096 wavefront chunk 4096
+q cornell 1024 1024 4096 wavefront chunk 1024
+q cornell 1024 1024 4096 wavefront chunk 256
+q cornell 1024 1024 4096 wavefront chunk 128
+q cornell 1024 1024 4096 wavefront chunk 64
+q cornell 1024 1024 512 wavefront
+q cornell 1024 1024 512 wavefront chunk 512
+q random 1920 1080 64 wavefront
+q random 1920 1080 64 wavefront chunk 64
