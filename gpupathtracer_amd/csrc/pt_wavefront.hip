@@ -62,7 +62,7 @@ struct WfState {
     int32_t   round_limit;    // rounds after which a group gives up (a lane was lost: cannot happen, must not hang)
     int32_t   ns_end;         // the sample count at which a lane's work ends: the pixel's last sample, or the end of a chunk (k_wf_chunks)
     int32_t   chunk_samples, n_chunks;    // k_wf_chunks: samples per work item, items per group
-    unsigned* words;          // k_wf_chunks: [0] the ticket, [4 ..) a progress word per group
+    unsigned* words;          // k_wf_chunks: [0] the ticket, [1] [2] cost sum and count, [4 ..) a progress word per group, then a cost word per group
     unsigned long long* group_states;     // k_wf_chunks: a group's random-stream states and running sums between its chunks (WF_GROUP_STATE_WORDS each)
 };
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
     __shared__ float4 faces[WfFaces<F, W>::float4s];
     __shared__ GroupQueues<NQ> gq;
     __shared__ LdsLanes<true> lanes;
-    __shared__ unsigned s_item;
+    __shared__ unsigned s_item, s_prio;
     unsigned* const words = w.words;
     unsigned long long* const group_states = w.group_states;
     const int n_chunks = w.n_chunks, chunk_samples = w.chunk_samples;
@@ -415,12 +415,26 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
     }
     const unsigned groups = ((unsigned)ra.n_wave_tiles * 64u + (unsigned)WF_GROUP_LDS - 1u) / (unsigned)WF_GROUP_LDS;
     const unsigned n_items = groups * (unsigned)n_chunks;
+    // words: [0] the ticket, [1] [2] sum and count of the groups' first-chunk costs, [4 ..) a progress word per group, then a
+    // cost word per group: a group's first chunk is timed and its later chunks run at a wave priority that grows with that
+    // time over the running mean, so that the expensive groups' chains of chunks are served first (as in k_render_chunks;
+    // which wave issues first changes no value)
     unsigned* const progress = words + 4;
+    unsigned* const cost = words + 4 + groups;
+    unsigned long long item_began = 0;
+    unsigned finished_cost = 0;
     bool finished_one = false;
     unsigned finished_grp = 0, finished_c = 0;
     while (true) {
         if (threadIdx.x == 0) {
-            if (finished_one) __hip_atomic_store(&progress[finished_grp], finished_c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (finished_one) {
+                if (finished_c == 0) {
+                    __hip_atomic_store(&cost[finished_grp], finished_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&words[1], finished_cost); atomicAdd(&words[2], 1u);
+                }
+                __hip_atomic_store(&progress[finished_grp], finished_c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_prio = 0;
             s_item = atomicAdd(&words[0], 1u);
         }
         if (threadIdx.x < 2) gq.n_ext[threadIdx.x] = 0;
@@ -440,10 +454,23 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
                     __builtin_amdgcn_s_sleep(64);
                     if (++spins > (1u << 23)) { *w.lost = 2; break; }
                 }
+                const unsigned long long mine = __hip_atomic_load(&cost[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long sum = __hip_atomic_load(&words[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long cnt = __hip_atomic_load(&words[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long tenths = sum ? 10ull * mine * cnt / sum : 10ull;
+                s_prio = tenths >= 15 ? 3u : tenths >= 12 ? 2u : tenths >= 9 ? 1u : 0u;
             }
             __syncthreads();
             __threadfence();                                      // every wave: the loads below come after the word
         }
+        {
+            const unsigned prio = (unsigned)__builtin_amdgcn_readfirstlane((int)s_prio);
+            if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+            else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+            else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        item_began = clock64();
         w.ns_end = min(ra.ns, (c + 1) * chunk_samples);
         const uint32_t group_first = grp * (uint32_t)WF_GROUP_LDS;
         unsigned long long* const st_rng = group_states + (size_t)grp * WF_GROUP_STATE_WORDS;
@@ -497,6 +524,7 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
         __threadfence();                                          // every lane's stores before the word
         __syncthreads();
         finished_one = true; finished_grp = grp; finished_c = (unsigned)c;
+        finished_cost = (unsigned)min((unsigned long long)0xffffffffu, (clock64() - item_began) >> 6);
     }
 }
 
@@ -618,7 +646,7 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
     const int chunk_samples = pieces > 1 ? (ra.ns + pieces - 1) / pieces : ra.ns;
     if (pieces > 1) pieces = (ra.ns + chunk_samples - 1) / chunk_samples;
     const size_t states_bytes = pieces > 1 ? (size_t)groups * WF_GROUP_STATE_WORDS * sizeof(unsigned long long) : 0;
-    const size_t words_bytes = pieces > 1 ? (((size_t)4 + groups) * sizeof(unsigned) + 255) / 256 * 256 : 0;
+    const size_t words_bytes = pieces > 1 ? (((size_t)4 + 2 * (size_t)groups) * sizeof(unsigned) + 255) / 256 * 256 : 0;      // ticket, cost sum and count; a progress and a cost word per group
     const size_t bytes = (in_lds ? 0 : (size_t)n_lanes * per_lane) + 256 + states_bytes + words_bytes;
     if (sc->wf_workspace_bytes < bytes) {
         if (sc->wf_workspace) { (void)hipFree(sc->wf_workspace); sc->wf_workspace = nullptr; sc->wf_workspace_bytes = 0; }
