@@ -393,27 +393,32 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
 // three components as rows of 256 floats), and chunk c of a group starts once the group's progress word says chunk
 // c - 1 has been stored.  The wait cannot deadlock (the item waited for has a smaller number, so a running workgroup
 // holds it, and chains of waits end at a chunk 0) and is bounded by progress all the same: a word that stands still
-// for 2^23 polls raises *w.lost = 2.  Only for kernels that keep their lanes in LDS (lanes_in_lds).
+// for 2^23 polls raises *w.lost = 2.  Kernels whose lanes live in global memory (the tree families) keep the states
+// where they are: a group's lanes have their own places in the state arrays whichever workgroup runs the chunk.
 // The loop keeps the shape of k_render_chunks' (one errand of thread 0 per round, between two barriers): see there.
 constexpr int WF_GROUP_STATE_WORDS = WF_GROUP_LDS + 3 * (WF_GROUP_LDS / 2);      // 5 120 bytes
 template <uint32_t F, class W>
 __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView sv, RenderArgs ra, WfState w, float* __restrict__ out)
 {
-    static_assert(lanes_in_lds<F>::value, "the chunked staged kernel keeps its lanes in LDS");
     constexpr int NQ = ShadeQueues<F>::value;
+    constexpr bool IN_LDS = lanes_in_lds<F>::value;
+    __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[WfFaces<F, W>::float4s];
     __shared__ GroupQueues<NQ> gq;
-    __shared__ LdsLanes<true> lanes;
+    __shared__ LdsLanes<IN_LDS> lanes;
     __shared__ unsigned s_item, s_prio;
     unsigned* const words = w.words;
     unsigned long long* const group_states = w.group_states;
     const int n_chunks = w.n_chunks, chunk_samples = w.chunk_samples;
-    w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit = lanes.hit;
-    w.rng = lanes.rng; w.pix = lanes.pix;
+    if constexpr (IN_LDS) {
+        w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit = lanes.hit;
+        w.rng = lanes.rng; w.pix = lanes.pix;
+    }
+    int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;
     if constexpr (WfFaces<F, W>::used) {
         for (int k = threadIdx.x; k < WfFaces<F, W>::float4s; k += blockDim.x) { const float* f = sv.sig_faces + 4 * k; faces[k] = make_float4(f[0], f[1], f[2], f[3]); }
     }
-    const unsigned groups = ((unsigned)ra.n_wave_tiles * 64u + (unsigned)WF_GROUP_LDS - 1u) / (unsigned)WF_GROUP_LDS;
+    const unsigned groups = ((unsigned)ra.n_wave_tiles * 64u + (unsigned)w.group_lanes - 1u) / (unsigned)w.group_lanes;
     const unsigned n_items = groups * (unsigned)n_chunks;
     // words: [0] the ticket, [1] [2] sum and count of the groups' first-chunk costs, [4 ..) a progress word per group, then a
     // cost word per group: a group's first chunk is timed and its later chunks run at a wave priority that grows with that
@@ -472,28 +477,35 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
         }
         item_began = clock64();
         w.ns_end = min(ra.ns, (c + 1) * chunk_samples);
-        const uint32_t group_first = grp * (uint32_t)WF_GROUP_LDS;
-        unsigned long long* const st_rng = group_states + (size_t)grp * WF_GROUP_STATE_WORDS;
-        float* const st_sum = reinterpret_cast<float*>(st_rng + WF_GROUP_LDS);
-        // generate: this workgroup's thread j is the group's lane j
-        {
-            const uint32_t j = threadIdx.x;
+        const uint32_t group_first = grp * (uint32_t)w.group_lanes;     // the group's first lane of the launch
+        const uint32_t first = IN_LDS ? 0u : group_first;                 // ... and in the state arrays
+        unsigned long long* const st_rng = IN_LDS ? group_states + (size_t)grp * WF_GROUP_STATE_WORDS : nullptr;
+        float* const st_sum = IN_LDS ? reinterpret_cast<float*>(st_rng + WF_GROUP_LDS) : nullptr;
+        // generate.  A kernel whose lanes live in global memory finds the states its group's last chunk left where it left them.
+        for (uint32_t j = threadIdx.x; j < (uint32_t)w.group_lanes; j += blockDim.x) {
+            const uint32_t l = first + j;
             const int wave = (int)((group_first + j) >> 6), lane = (int)(j & 63);
             int x = 0, ytop = 0;
             const bool live = wave < ra.n_wave_tiles && wave_pixel(ra, wave, lane, x, ytop);
             bool go = false;
             if (live) {
                 const unsigned i = (unsigned)(ytop * ra.nx + x);
-                w.pix[j] = i;
+                w.pix[l] = i;
                 Pcg rng;
                 rng.seed(i);
                 V3 acc = mk(0, 0, 0);
                 if (c > 0) {
-                    rng.state = st_rng[j];
-                    acc = mk(st_sum[j], st_sum[WF_GROUP_LDS + j], st_sum[2 * WF_GROUP_LDS + j]);
+                    if constexpr (IN_LDS) {
+                        rng.state = st_rng[j];
+                        acc = mk(st_sum[j], st_sum[WF_GROUP_LDS + j], st_sum[2 * WF_GROUP_LDS + j]);
+                    } else {
+                        rng.state = w.rng[l];
+                        const float4 a4 = w.acc[l];
+                        acc = mk(a4.x, a4.y, a4.z);
+                    }
                 }
-                go = end_path(sv, ra, w, j, i, acc, c * chunk_samples, mk(0, 0, 0), rng, out, true);
-                w.rng[j] = rng.state;
+                go = end_path(sv, ra, w, l, i, acc, c * chunk_samples, mk(0, 0, 0), rng, out, true);
+                w.rng[l] = rng.state;
             }
             queue_push(gq.ext[0], &gq.n_ext[0], live && go, j);
         }
@@ -502,16 +514,16 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
         for (int round = 0; ; round++) {
             if (gq.n_ext[cur] == 0) break;                          // every lane of the group has reached the item's last sample
             if (round >= w.round_limit) { if (threadIdx.x == 0) *w.lost = 1; break; }
-            extend_stage<F, W, false>(sv, ra, w, out, nullptr, faces, gq, cur, 0u, nullptr);
+            extend_stage<F, W, false>(sv, ra, w, out, my_stack, faces, gq, cur, first, nullptr);
             __syncthreads();
-            for (int q = 0; q < NQ; q++) shade_stage<F, W, false>(sv, ra, w, q, out, faces, gq, cur, 0u, nullptr);
+            for (int q = 0; q < NQ; q++) shade_stage<F, W, false>(sv, ra, w, q, out, faces, gq, cur, first, nullptr);
             __syncthreads();
             if (threadIdx.x == 0) gq.n_ext[cur] = 0;
             if (threadIdx.x < NQ) gq.n_shade[threadIdx.x] = 0;
             cur ^= 1;
             __syncthreads();
         }
-        if (c < n_chunks - 1) {                                     // the lanes' states wait for the group's next chunk
+        if (IN_LDS && c < n_chunks - 1) {                           // the lanes' states wait for the group's next chunk
             const uint32_t j = threadIdx.x;
             const int wave = (int)((group_first + j) >> 6), lane = (int)(j & 63);
             int x = 0, ytop = 0;
@@ -549,15 +561,23 @@ void launch_chunks(const SceneView& sv, const RenderArgs& ra, const WfState& w, 
 {
     hipLaunchKernelGGL((k_wf_chunks<F, W>), dim3(workgroups), dim3(256), 0, st, sv, ra, w, out);
 }
-// The variants whose kernels keep their lanes in LDS (lanes_in_lds) have a chunked form.
-bool launch_chunks_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned workgroups, float* out, hipStream_t st)
+void launch_chunks_variant(int variant, const SceneView& sv, const RenderArgs& ra, const WfState& w, unsigned workgroups, float* out, hipStream_t st)
 {
     using namespace ptk;
     switch (variant) {
-    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_chunks<M_CORNELL, CornellWorld>(sv, ra, w, workgroups, out, st); return true;
-    case V_CORNELL: launch_chunks<M_CORNELL, AnyWorld>(sv, ra, w, workgroups, out, st); return true;
-    case V_SPHERES: launch_chunks<M_SPHERES, AnyWorld>(sv, ra, w, workgroups, out, st); return true;
-    default: return false;
+    case V_CORNELL_WORLD: case V_CORNELL_WORLD_FLAT: launch_chunks<M_CORNELL, CornellWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_CORNELL: launch_chunks<M_CORNELL, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_SPHERES: launch_chunks<M_SPHERES, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_SPHERES_LBVH: launch_chunks<M_SPHERES_LBVH, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_SPHERES_LBVH4: launch_chunks<M_SPHERES_LBVH4, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_TRIMESH: launch_chunks<M_TRIMESH, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_TRIMESH4: launch_chunks<M_TRIMESH4, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_FINAL: launch_chunks<M_FINAL, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_FINAL_LBVH: launch_chunks<M_FINAL_LBVH, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_FINAL_LBVH4: launch_chunks<M_FINAL_LBVH4, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_ALL: launch_chunks<M_ALL, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    case V_ALL_LBVH4: launch_chunks<M_ALL_LBVH4, AnyWorld>(sv, ra, w, workgroups, out, st); break;
+    default: launch_chunks<M_ALL_LBVH, AnyWorld>(sv, ra, w, workgroups, out, st); break;
     }
 }
 
@@ -630,22 +650,23 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
     // frame after frame pays for it once); it grows when a larger shard comes along.
     const bool image = (kernel_mask & F_IMAGE) != 0;      // the kernels compiled with image textures keep the uv field
     const size_t per_lane = 16 * (image ? 6 : 5) + 8 + 4;
-    // Chunks of samples (k_wf_chunks), for the kernels that keep their lanes in LDS: asked for (chunk_samples), or by
-    // itself when the groups are few for the GPU (under two rounds of its resident workgroups the launch ends with its
-    // slowest group either way) and the samples many; about 32 rounds of work items then.  Rectangle scene 1024^2 x4096:
-    // 348 ms whole groups, the same paths as a 4096^2 frame at 256 samples (groups to spare) 287.
+    // Chunks of samples (k_wf_chunks): asked for (chunk_samples), or by itself when the groups are few for the GPU -- between
+    // two and sixteen rounds of its resident workgroups: under two the launch ends with its slowest group either way, with
+    // many rounds its end is a small part of it -- and the samples many; about 32 rounds of work items then.  Rectangle
+    // scene 1024^2 x4096: 348 ms whole groups, the same paths as a 4096^2 frame at 256 samples (groups to spare) 287; random
+    // spheres in the tree 1920x1080 x256 215 against 189 as 3840x2160 x64, final in the tree 260 against 210; 2 M triangles
+    // 3840x2160 (25 rounds) 147 against 158.
     int pieces = 1;
     const long long resident = 256LL * wf_min_blocks(kernel_mask);
-    if (in_lds && !ra.stage_stats && ra.ns >= 2 && (sc->variant == ptk::V_CORNELL_WORLD || sc->variant == ptk::V_CORNELL_WORLD_FLAT ||
-                                                      sc->variant == ptk::V_CORNELL || sc->variant == ptk::V_SPHERES)) {
+    if (!ra.stage_stats && ra.ns >= 2) {
         if (ra.wf_chunk_samples > 0) pieces = (ra.ns + ra.wf_chunk_samples - 1) / ra.wf_chunk_samples;
-        else if ((long long)groups >= 2 * resident && ra.ns >= 128)
+        else if ((long long)groups >= 2 * resident && (long long)groups <= 16 * resident && ra.ns >= 128)
             pieces = (int)std::min<long long>((32 * resident + groups - 1) / groups, ra.ns / 32);
         pieces = (int)std::min<long long>(std::max(pieces, 1), 0x7fffffffLL / groups);      // work items are numbered in 32 bits
     }
     const int chunk_samples = pieces > 1 ? (ra.ns + pieces - 1) / pieces : ra.ns;
     if (pieces > 1) pieces = (ra.ns + chunk_samples - 1) / chunk_samples;
-    const size_t states_bytes = pieces > 1 ? (size_t)groups * WF_GROUP_STATE_WORDS * sizeof(unsigned long long) : 0;
+    const size_t states_bytes = (pieces > 1 && in_lds) ? (size_t)groups * WF_GROUP_STATE_WORDS * sizeof(unsigned long long) : 0;     // lanes in global memory keep their states in place
     const size_t words_bytes = pieces > 1 ? (((size_t)4 + 2 * (size_t)groups) * sizeof(unsigned) + 255) / 256 * 256 : 0;      // ticket, cost sum and count; a progress and a cost word per group
     const size_t bytes = (in_lds ? 0 : (size_t)n_lanes * per_lane) + 256 + states_bytes + words_bytes;
     if (sc->wf_workspace_bytes < bytes) {
@@ -671,7 +692,7 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
     w.chunk_samples = chunk_samples; w.n_chunks = pieces;
     w.words = nullptr; w.group_states = nullptr;
     if (pieces > 1) {
-        w.group_states = reinterpret_cast<unsigned long long*>(take(states_bytes));
+        if (states_bytes) w.group_states = reinterpret_cast<unsigned long long*>(take(states_bytes));
         w.words = reinterpret_cast<unsigned*>(take(words_bytes));
         if (!hip_ok2(hipMemsetAsync(w.words, 0, words_bytes, st), "hipMemsetAsync(chunk words)")) return PT_ERR_HIP;
     }
@@ -686,7 +707,7 @@ int render_wavefront(PtScene* sc, const RenderArgs& ra, float* d_out, hipStream_
 
     if (pieces > 1) {
         const unsigned workgroups = (unsigned)std::min<long long>((long long)groups * pieces, resident);     // persistent: they draw work items from the ticket
-        if (!launch_chunks_variant(sc->variant, sc->view, ra, w, workgroups, d_out, st)) { pt::set_error("wavefront: no chunked kernel for this scene"); return PT_ERR_UNSUPPORTED; }
+        launch_chunks_variant(sc->variant, sc->view, ra, w, workgroups, d_out, st);
     } else {
         launch_variant(sc->variant, sc->view, ra, w, groups, d_out, st);
     }

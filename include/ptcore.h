@@ -234,8 +234,7 @@ typedef struct PtRenderParams {
     int32_t batch_index, batch_count;
     int32_t raw_sum;
     int32_t chunk_samples; /* PT_SCHEDULE_CHUNKS, _REFILL, _WALK (and what AUTO picks): samples per chunk; 0 = the library's choice.
-                            * PT_PIPELINE_WAVEFRONT, rectangle scenes and sphere lists: the same for its groups of pixels
-                            * (>= ns: whole groups) */
+                            * PT_PIPELINE_WAVEFRONT: the same for its groups of pixels (>= ns: whole groups) */
     int32_t stage_stats;   /* PT_PIPELINE_WAVEFRONT: != 0 counts what the stages did, for pt_render_stage_stats (a kernel of
                             * its own: the counting costs the rectangle scene's staged render about 6 % of its rate)      */
     int32_t slot_block_tiles; /* PT_SCHEDULE_REFILL, _WALK (and AUTO where it picks them): how lanes draw pixel slots.  0 = the library's choice;

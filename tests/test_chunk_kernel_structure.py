@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 # k_render_chunks instantiations per translation unit: the rectangle scenes' three (generic walk, compiled-in walk,
 # its branchless form), the sphere scenes' list walk and binary tree in one unit, one each elsewhere
-EXPECTED = {"pt_k_cornell": 3, "pt_k_spheres": 2, "pt_wavefront": 3}      # the staged pipeline's chunk kernel: rectangle scenes (two walks), sphere lists
+EXPECTED = {"pt_k_cornell": 3, "pt_k_spheres": 2, "pt_wavefront": 13}     # the staged pipeline's chunk kernel: one per scene variant
 
 
 @pytest.fixture(scope="module")

@@ -381,7 +381,7 @@ def test_wavefront_scheduler_bit_exact(oracle, name, aspect, nx, ny, ns):
     assert_bit_exact(img, oracle.render(d, nx, ny, ns), name + " (wavefront)")
 
 
-@pytest.mark.parametrize("which", ["cornell", "cornell_permuted", "random"])
+@pytest.mark.parametrize("which", ["cornell", "cornell_permuted", "random", "random_tree", "final", "final_tree", "trimesh"])
 def test_wavefront_scheduler_in_chunks_bit_exact(oracle, which):
     """The staged scheduler with every group's samples cut into chunks (k_wf_chunks: persistent workgroups draw (chunk,
     group) items from a counter, the lanes' random-stream states and running sums wait in device memory between a
@@ -389,6 +389,15 @@ def test_wavefront_scheduler_in_chunks_bit_exact(oracle, which):
     bounce limits 0 and 1, a shard, and the library's own cuts on a frame of many groups."""
     if which == "random":
         d = pt.builtin_scene("random", 2.0)                       # over its flat list: the sphere kernels keep their lanes in LDS too
+    elif which == "random_tree":                                  # the tree families keep their lanes in global memory, where the states wait in place
+        d = pt.builtin_scene("random", 2.0, accel=abi.ACCEL_LBVH)
+    elif which == "final":
+        d = pt.builtin_scene("final", 16 / 9, earth_rgb=_earth_map_512x256())
+    elif which == "final_tree":
+        d = pt.builtin_scene("final", 16 / 9, earth_rgb=_earth_map_512x256(), accel=abi.ACCEL_LBVH)
+    elif which == "trimesh":
+        d = pt.trimesh_scene(12, 1.0)
+        d.c.accel = abi.ACCEL_LBVH
     elif which == "cornell_permuted":                             # the rectangle scene's kinds in another order: the generic walk
         from tests._desc_tools import OwnedDesc
         g = OwnedDesc(pt.builtin_scene("cornell", 1.0))
@@ -410,7 +419,14 @@ def test_wavefront_scheduler_in_chunks_bit_exact(oracle, which):
                          "%s staged in chunks, bounce limit %d" % (which, depth))
     ref = oracle.render(d, 72, 40, 7, shard_index=1, shard_count=3)
     assert_bit_exact(sc.render(72, 40, 7, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=2, shard_index=1, shard_count=3), ref, which + " staged shard in chunks")
-    if which != "random":
+    if which in ("random_tree", "final_tree"):
+        # 1920x1080 is 4 050 groups of 512 lanes for 1 024 resident workgroups: the library cuts 128 samples into 4
+        whole = sc.render(1920, 1080, 128, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=128)
+        assert sc.stats().n_chunks == 0
+        cut = sc.render(1920, 1080, 128, pipeline=abi.PIPELINE_WAVEFRONT)
+        assert sc.stats().n_chunks == 4
+        assert_bit_exact(cut, whole, which + " 1920x1080x128 staged, the library's cuts")
+    if which in ("cornell", "cornell_permuted"):
         # 4 096 groups for 1 280 resident workgroups and 128 samples: the library cuts by itself (into 4 here)
         whole = sc.render(1024, 1024, 128, pipeline=abi.PIPELINE_WAVEFRONT, chunk_samples=128)
         assert sc.stats().n_chunks == 0
