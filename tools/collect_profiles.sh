@@ -38,8 +38,8 @@ cp "$(stats_csv $O/prof_configs)" $O/configs_1gpu_kernel_stats.csv
 echo "== sharding estimates"
 $T 600 python3 tools/sharding_estimates.py > $O/sharding_estimates.json
 echo "== staged pipeline"
-$T 900 python3 tools/pmc_collect.py $O/pmc_wf k_wf_groups -- python3 tools/wavefront_render.py 512 > $O/pmc_wf.log
-cp $O/pmc_wf/summary.json $O/pmc_staged_cornell1024x512_k_wf_groups.json
+$T 900 python3 tools/pmc_collect.py $O/pmc_wf k_wf_chunks -- python3 tools/wavefront_render.py 512 > $O/pmc_wf.log
+cp $O/pmc_wf/summary.json $O/pmc_staged_cornell1024x512_k_wf_chunks.json
 $T 900 python3 tools/pmc_collect.py $O/pmc_wf_c1 k_wf_groups -- python3 bench/configs.py --only c1 --quick --pipeline wavefront > $O/pmc_wf_c1.log
 cp $O/pmc_wf_c1/summary.json $O/pmc_staged_c1_rtiow_lbvh_k_wf_groups.json
 $T 600 python3 bench/configs.py --pipeline wavefront > $O/configs_1gpu_staged.jsonl
