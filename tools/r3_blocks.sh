@@ -1,12 +1,12 @@
 #!/bin/bash
-# The final scene's chunk kernel over the 4-wide tree with 4 (tree build) / 2 / 1 waves per workgroup, same box.
+# Staged tree kernels in chunks: groups of 512 lanes (the library's choice for sphere and box trees) against 256, at 4 workgroups per CU.
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }
-for lib in "" tools/exp/libptcore_cw2.so tools/exp/libptcore_cw1.so; do
-  export PT_LIBPTCORE_PATH=$lib
-  [ -z "$lib" ] && unset PT_LIBPTCORE_PATH
-  echo "== lib: ${lib:-tree}"
-  q final 1920 1080 256 lbvh
-  q final 1920 1080 256 lbvh schedule 4 chunk 32
+export PT_LIBPTCORE_PATH=tools/exp/libptcore_w4.so
+for g in 512 256; do
+  export PT_WF_GROUP=$g
+  echo "== groups of $g lanes"
+  q random 1920 1080 256 lbvh wavefront
+  q final 1920 1080 256 lbvh wavefront
 done
