@@ -51,6 +51,7 @@ struct WfState {
     float4*   ray_o;      // origin, time
     float4*   ray_d;      // direction (w unused)
     int4*     hit;        // bits of t, id, face (signature worlds: 8 * entry + face), unused
+    int2*     hit2;       // kernels with their lanes in LDS: bits of t; 8 * entry + face (signature worlds) or id << 3 | face
     int4*     uv;         // kernels with image textures: the earlier uv-writing hit (id, face, bits of t)
     float4*   thr;        // running product of the path (accumCol of color()), bounces done (integer bits)
     float4*   acc;        // pixel sum, samples finished (integer bits)
@@ -72,12 +73,14 @@ template <uint32_t F> struct ShadeQueues {
 };
 
 // A group's queues, in its workgroup's LDS.
-template <int NQ>
+template <int NQ, int CAP>
 struct GroupQueues {
-    uint16_t ext[2][WF_GROUP_MAX];      // the extend queue being read and the one being filled
-    uint16_t shade[NQ][WF_GROUP_MAX];
+    uint16_t ext[2][CAP];               // the extend queue being read and the one being filled
+    uint16_t shade[NQ][CAP];
     unsigned n_ext[2], n_shade[NQ];
 };
+// most lanes of a group of kernel F: the kernels that keep their lanes in LDS run groups of WF_GROUP_LDS lanes only
+template <uint32_t F> struct GroupCap { static constexpr int value = ((F & (F_LBVH | F_REFBVH | F_IMAGE)) == 0) ? WF_GROUP_LDS : WF_GROUP_MAX; };
 
 // Lane state of a group in its workgroup's LDS, for kernels small enough to afford it (23 KB a group):
 // the stages then read and write a lane's fields where its queues live, and nothing of a path but the
@@ -86,7 +89,7 @@ struct GroupQueues {
 template <bool ON> struct LdsLanes {};
 template <> struct LdsLanes<true> {
     float4   ray_o[WF_GROUP_LDS], ray_d[WF_GROUP_LDS], thr[WF_GROUP_LDS], acc[WF_GROUP_LDS];
-    int4     hit[WF_GROUP_LDS];
+    int2     hit[WF_GROUP_LDS];
     uint64_t rng[WF_GROUP_LDS];
     uint32_t pix[WF_GROUP_LDS];
 };
@@ -162,7 +165,7 @@ __device__ __forceinline__ bool end_path(const SceneView& sv, const RenderArgs& 
 // The search: world->hit for the lanes of the group's extend queue `cur`.
 template <uint32_t F, class W, bool STATS>
 __device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, float* __restrict__ out,
-                                             int* my_stack, const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first,
+                                             int* my_stack, const float4* faces, GroupQueues<ShadeQueues<F>::value, GroupCap<F>::value>& gq, int cur, uint32_t first,
                                              unsigned* group_stats)
 {
     const unsigned count = gq.n_ext[cur];
@@ -203,7 +206,8 @@ __device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderAr
                 } else {
                     kind = (mtype == PT_MAT_METAL) ? Q_METAL : (mtype == PT_MAT_DIELECTRIC) ? Q_DIELECTRIC
                          : (mtype == PT_MAT_ISOTROPIC) ? Q_ISOTROPIC : Q_LAMBERT;
-                    w.hit[l] = make_int4(__float_as_int(h.t), h.id, WfFaces<F, W>::used ? h.sig_code : h.face, 0);
+                    if constexpr (lanes_in_lds<F>::value) w.hit2[l] = make_int2(__float_as_int(h.t), WfFaces<F, W>::used ? h.sig_code : ((h.id << 3) | h.face));
+                    else w.hit[l] = make_int4(__float_as_int(h.t), h.id, WfFaces<F, W>::used ? h.sig_code : h.face, 0);
                     if (F & F_IMAGE) w.uv[l] = make_int4(h.uv_id, h.uv_face, __float_as_int(h.uv_t), 0);
                 }
             } else {
@@ -236,7 +240,7 @@ __device__ __forceinline__ void extend_stage(const SceneView& sv, const RenderAr
 // Shading of material queue q: every wave shades one material kind.
 template <uint32_t F, class W, bool STATS>
 __device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArgs& ra, const WfState& w, int q, float* __restrict__ out,
-                                            const float4* faces, GroupQueues<ShadeQueues<F>::value>& gq, int cur, uint32_t first, unsigned* group_stats)
+                                            const float4* faces, GroupQueues<ShadeQueues<F>::value, GroupCap<F>::value>& gq, int cur, uint32_t first, unsigned* group_stats)
 {
     const unsigned count = gq.n_shade[q];
     if constexpr (STATS) { if (threadIdx.x == 0 && count != 0) { atomicAdd(&group_stats[4 + q], count); atomicAdd(&group_stats[8 + q], (count + 63u) >> 6); } }
@@ -249,7 +253,13 @@ __device__ __forceinline__ void shade_stage(const SceneView& sv, const RenderArg
             j = gq.shade[q][idx];
             const uint32_t l = first + j;
             const float4 o4 = w.ray_o[l], d4 = w.ray_d[l], t4 = w.thr[l];
-            const int4 h4 = w.hit[l];
+            int4 h4;
+            if constexpr (lanes_in_lds<F>::value) {
+                const int2 h2 = w.hit2[l];
+                h4 = WfFaces<F, W>::used ? make_int4(h2.x, 0, h2.y, 0) : make_int4(h2.x, h2.y >> 3, h2.y & 7, 0);
+            } else {
+                h4 = w.hit[l];
+            }
             const uint32_t i = w.pix[l];
             Ray ray;
             ray.o = mk(o4.x, o4.y, o4.z); ray.d = mk(d4.x, d4.y, d4.z); ray.time = o4.w;
@@ -308,10 +318,10 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_groups(SceneView s
     constexpr int NQ = ShadeQueues<F>::value;
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[WfFaces<F, W>::float4s];
-    __shared__ GroupQueues<NQ> gq;
+    __shared__ GroupQueues<NQ, GroupCap<F>::value> gq;
     __shared__ LdsLanes<lanes_in_lds<F>::value> lanes;
     if constexpr (lanes_in_lds<F>::value) {                   // the fields are this workgroup's own: lane numbers start at 0
-        w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit = lanes.hit;
+        w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit2 = lanes.hit;
         w.rng = lanes.rng; w.pix = lanes.pix;
     }
     if constexpr (WfFaces<F, W>::used) {
@@ -404,14 +414,14 @@ __global__ __launch_bounds__(256, wf_min_blocks(F)) void k_wf_chunks(SceneView s
     constexpr bool IN_LDS = lanes_in_lds<F>::value;
     __shared__ int lds_stack[(F & (F_LBVH | F_REFBVH)) ? 4 * 64 * LBVH_LDS_STACK : 1];
     __shared__ float4 faces[WfFaces<F, W>::float4s];
-    __shared__ GroupQueues<NQ> gq;
+    __shared__ GroupQueues<NQ, GroupCap<F>::value> gq;
     __shared__ LdsLanes<IN_LDS> lanes;
     __shared__ unsigned s_item, s_prio;
     unsigned* const words = w.words;
     unsigned long long* const group_states = w.group_states;
     const int n_chunks = w.n_chunks, chunk_samples = w.chunk_samples;
     if constexpr (IN_LDS) {
-        w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit = lanes.hit;
+        w.ray_o = lanes.ray_o; w.ray_d = lanes.ray_d; w.thr = lanes.thr; w.acc = lanes.acc; w.hit2 = lanes.hit;
         w.rng = lanes.rng; w.pix = lanes.pix;
     }
     int* my_stack = (F & (F_LBVH | F_REFBVH)) ? &lds_stack[(threadIdx.x >> 6) * 64 * LBVH_LDS_STACK + (threadIdx.x & 63)] : nullptr;

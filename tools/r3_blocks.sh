@@ -1,12 +1,14 @@
 #!/bin/bash
-# Staged tree kernels in chunks: groups of 512 lanes (the library's choice for sphere and box trees) against 256, at 4 workgroups per CU.
+# Staged kernels with the trimmed LDS records at 5 (tree build) and 6 workgroups per CU, same box.
 set -e
 T="timeout -k 10"
 q() { $T 300 python3 tools/quick_time.py "$@"; }
-export PT_LIBPTCORE_PATH=tools/exp/libptcore_w4.so
-for g in 512 256; do
-  export PT_WF_GROUP=$g
-  echo "== groups of $g lanes"
-  q random 1920 1080 256 lbvh wavefront
-  q final 1920 1080 256 lbvh wavefront
+for lib in "" tools/exp/libptcore_w6.so; do
+  export PT_LIBPTCORE_PATH=$lib
+  [ -z "$lib" ] && unset PT_LIBPTCORE_PATH
+  echo "== lib: ${lib:-tree}"
+  q cornell 1024 1024 4096 wavefront
+  q cornell 1024 1024 512 wavefront
+  q cornell_spheres 1024 1024 256 wavefront
+  q random 1920 1080 32 wavefront
 done
